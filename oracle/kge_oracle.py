@@ -1,0 +1,304 @@
+"""CPU ORACLE for the open-KGE hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module; the product path (``open_knowledge_graph_embeddings_amd``) never does and fails loudly when its
+HIP library is missing.
+
+What this is: a NumPy restatement (explicit forward AND hand-written backward, no autograd) of the
+reference's batched prefix-scoring training step and filtered-rank evaluation.  Every function cites
+the reference lines it follows (paths relative to /root/reference).
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against golden
+vectors produced by running the reference itself in the build container
+(``tests/golden/make_golden.py``; vectors G1, G2, G3, G5, G7 of SURVEY.md section 8c).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+COMPLEX, DISTMULT = 0, 1
+DIR_PO, DIR_SP = 0, 1
+LOSS_BCE, LOSS_KL = 0, 1
+
+KIND_NAMES = {"complex": COMPLEX, "distmult": DISTMULT}
+LOSS_NAMES = {"bce": LOSS_BCE, "kl": LOSS_KL}
+
+
+# ------------------------------------------------------------------------------------------------
+# embedder: gather -> dropout            openkge/model.py:455-480 (_encode), :502-510 (encode_obj)
+# ------------------------------------------------------------------------------------------------
+def encode(table, ids, keep=None, p=0.0):
+    """``embedding(ids)`` followed by ``dropout(p)``: rows * keep / (1 - p).
+
+    model.py:457-462.  ``keep`` is the Bernoulli keep-mask (bool/uint8, same shape as the rows) or
+    None for p == 0 / eval mode.  torch's CPU dropout multiplies by ``noise = bernoulli/(1-p)``.
+    """
+    rows = table[np.asarray(ids).reshape(-1).astype(np.int64)]
+    if keep is not None and p > 0.0:
+        scale = table.dtype.type(1.0) / table.dtype.type(1.0 - p)
+        rows = rows * (keep.astype(table.dtype) * scale)
+    return rows
+
+
+# ------------------------------------------------------------------------------------------------
+# scorers: prefix branch                 openkge/model.py:198-229 (ComplEx), :268-274 (DistMult)
+# ------------------------------------------------------------------------------------------------
+def prefix_query(kind, direction, ent, rel):
+    """Fold the two prefix slots into ONE query row so that score = query . candidate.
+
+    ComplEx sp (model.py:205-210):  (s1 r1) O1 + (s2 r1) O2 + (s1 r2) O2 - (s2 r2) O1
+        = [s1 r1 - s2 r2 , s2 r1 + s1 r2] . [O1, O2]
+    ComplEx po (model.py:211-216):  (o1 r1) S1 + (o2 r1) S2 + (o2 r2) S1 - (o1 r2) S2
+        = [o1 r1 + o2 r2 , o2 r1 - o1 r2] . [S1, S2]
+    DistMult (model.py:269-272): (s * r) . O   /  (r * o) . S
+    First half of the embedding is the real part, second half the imaginary part (model.py:202-204).
+    """
+    if kind == DISTMULT:
+        return ent * rel
+    h = ent.shape[1] // 2
+    e1, e2 = ent[:, :h], ent[:, h:]
+    r1, r2 = rel[:, :h], rel[:, h:]
+    if direction == DIR_SP:
+        return np.concatenate([e1 * r1 - e2 * r2, e2 * r1 + e1 * r2], axis=1)
+    return np.concatenate([e1 * r1 + e2 * r2, e2 * r1 - e1 * r2], axis=1)
+
+
+def prefix_query_backward(kind, direction, ent, rel, dq):
+    """Chain rule of :func:`prefix_query` (what autograd does for model.py:205-216 / :269-272)."""
+    if kind == DISTMULT:
+        return dq * rel, dq * ent
+    h = ent.shape[1] // 2
+    e1, e2 = ent[:, :h], ent[:, h:]
+    r1, r2 = rel[:, :h], rel[:, h:]
+    q1, q2 = dq[:, :h], dq[:, h:]
+    if direction == DIR_SP:
+        de = np.concatenate([q1 * r1 + q2 * r2, -q1 * r2 + q2 * r1], axis=1)
+        dr = np.concatenate([q1 * e1 + q2 * e2, -q1 * e2 + q2 * e1], axis=1)
+    else:
+        de = np.concatenate([q1 * r1 - q2 * r2, q1 * r2 + q2 * r1], axis=1)
+        dr = np.concatenate([q1 * e1 + q2 * e2, q1 * e2 - q2 * e1], axis=1)
+    return de, dr
+
+
+def score_prefix_4mm(kind, direction, ent, rel, cand):
+    """The reference's literal op sequence (4 matrix products for ComplEx), model.py:205-216."""
+    if kind == DISTMULT:
+        return (ent * rel) @ cand.T
+    h = ent.shape[1] // 2
+    a1, a2 = ent[:, :h], ent[:, h:]
+    r1, r2 = rel[:, :h], rel[:, h:]
+    c1, c2 = cand[:, :h], cand[:, h:]
+    if direction == DIR_SP:
+        return (a1 * r1) @ c1.T + (a2 * r1) @ c2.T + (a1 * r2) @ c2.T - (a2 * r2) @ c1.T
+    return (a1 * r1) @ c1.T + (a2 * r1) @ c2.T + (a2 * r2) @ c1.T - (a1 * r2) @ c2.T
+
+
+def score_prefix(kind, direction, ent, rel, cand):
+    """(b, N) scores of b prefixes against N candidate rows = query @ cand.T."""
+    return prefix_query(kind, direction, ent, rel) @ cand.T
+
+
+# ------------------------------------------------------------------------------------------------
+# loss                                    openkge/trainer.py:93-106
+# ------------------------------------------------------------------------------------------------
+def smooth_labels(y, smoothing):
+    """trainer.py:103-105: labels = (labels + 1/N) * (1 - eps)."""
+    if smoothing > 0:
+        y = (y + y.dtype.type(1.0 / y.shape[-1])) * y.dtype.type(1.0 - smoothing)
+    return y
+
+
+def log_softmax(x):
+    m = x.max(axis=1, keepdims=True)
+    z = x - m
+    return z - np.log(np.exp(z).sum(axis=1, keepdims=True))
+
+
+def loss_and_dscore(x, y, loss_kind, smoothing=0.0):
+    """Summed loss and d(loss)/d(score).
+
+    bce (trainer.py:102-106, BCEWithLogitsLoss(sum)): sum max(x,0) - x*y + log1p(exp(-|x|)),
+        gradient sigmoid(x) - y, labels smoothed first.
+    kl  (trainer.py:99-100,106, KLDivLoss(sum) on log_softmax): sum xlogy(y,y) - y*log_softmax(x)
+        with UNnormalised y (the normalisation is commented out, trainer.py:101),
+        gradient softmax(x) * sum_n y - y.
+    """
+    if loss_kind == LOSS_BCE:
+        y = smooth_labels(y, smoothing)
+        loss = np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))
+        sig = 1.0 / (1.0 + np.exp(-x))
+        return loss.sum(dtype=np.float64), (sig - y).astype(x.dtype)
+    lsm = log_softmax(x)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ylogy = np.where(y > 0, y * np.log(np.where(y > 0, y, 1.0)), 0.0)
+    loss = (ylogy - y * lsm).sum(dtype=np.float64)
+    g = np.exp(lsm) * y.sum(axis=1, keepdims=True) - y
+    return loss, g.astype(x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# one training step: forward + loss + backward
+#   openkge/trainer.py:48-113 (AddLossModule.forward) and :217-234 (normalise, backward)
+# ------------------------------------------------------------------------------------------------
+def step_forward_backward(kind, E, R, po, sp, cand_ids, labels, loss_kind=LOSS_BCE, smoothing=0.0,
+                          normalizer=None, p_ent=0.0, p_rel=0.0, keep_cand=None, keep_po_ent=None,
+                          keep_sp_ent=None, keep_po_rel=None, keep_sp_rel=None, want_grads=True):
+    """Returns dict(loss, outputs[B,N], dE, dR).
+
+    po = (rel_ids, obj_ids) or None, sp = (subj_ids, rel_ids) or None  (trainer.py:69-71);
+    output/label rows are ordered po first, then sp (trainer.py:91).  Candidates are encoded once
+    and shared by both directions (trainer.py:75-87), including their dropout mask.
+    normalizer defaults to B*N (dataset.py:935); the gradient is d(loss/normalizer).
+    """
+    dt = E.dtype
+    cand_ids = np.asarray(cand_ids).reshape(-1).astype(np.int64)
+    C = encode(E, cand_ids, keep_cand, p_ent)
+    parts = []
+    if po is not None:
+        rel_ids, obj_ids = po
+        r = encode(R, rel_ids, keep_po_rel, p_rel)
+        o = encode(E, obj_ids, keep_po_ent, p_ent)
+        parts.append((DIR_PO, o, r, np.asarray(obj_ids).reshape(-1).astype(np.int64),
+                      np.asarray(rel_ids).reshape(-1).astype(np.int64), keep_po_ent, keep_po_rel))
+    if sp is not None:
+        subj_ids, rel_ids = sp
+        s = encode(E, subj_ids, keep_sp_ent, p_ent)
+        r = encode(R, rel_ids, keep_sp_rel, p_rel)
+        parts.append((DIR_SP, s, r, np.asarray(subj_ids).reshape(-1).astype(np.int64),
+                      np.asarray(rel_ids).reshape(-1).astype(np.int64), keep_sp_ent, keep_sp_rel))
+    Q = np.concatenate([prefix_query(kind, d, e, r) for (d, e, r, *_rest) in parts], axis=0)
+    X = Q @ C.T
+    B, N = X.shape
+    if normalizer is None:
+        normalizer = float(B * N)
+    loss, g = loss_and_dscore(X, labels.astype(dt), loss_kind, smoothing)
+    out = {"loss": float(loss), "outputs": X}
+    if not want_grads:
+        return out
+    G = (g / dt.type(normalizer)).astype(dt)
+    dQ = G @ C
+    dC = G.T @ Q
+    dE = np.zeros_like(E)
+    dR = np.zeros_like(R)
+    sc_e = dt.type(1.0) / dt.type(1.0 - p_ent) if p_ent > 0 else dt.type(1.0)
+    sc_r = dt.type(1.0) / dt.type(1.0 - p_rel) if p_rel > 0 else dt.type(1.0)
+    if keep_cand is not None and p_ent > 0:
+        dC = dC * (keep_cand.astype(dt) * sc_e)
+    np.add.at(dE, cand_ids, dC)                       # embedding_dense_backward
+    row = 0
+    for (d, e, r, e_ids, r_ids, keep_e, keep_r) in parts:
+        n = e.shape[0]
+        de, dr = prefix_query_backward(kind, d, e, r, dQ[row:row + n])
+        if keep_e is not None and p_ent > 0:
+            de = de * (keep_e.astype(dt) * sc_e)
+        if keep_r is not None and p_rel > 0:
+            dr = dr * (keep_r.astype(dt) * sc_r)
+        np.add.at(dE, e_ids, de)
+        np.add.at(dR, r_ids, dr)
+        row += n
+    # padding_idx=PAD=0 rows never receive gradient (model.py:390-391); ids are >= 2 on this path.
+    out.update(dE=dE, dR=dR, dQ=dQ, G=G, Q=Q)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# dense Adagrad as configured by OptimRegime    utils/optim.py:29,139-160 + torch.optim.Adagrad
+# ------------------------------------------------------------------------------------------------
+def adagrad_step(p, g, state_sum, lr, weight_decay=1e-10, eps=1e-8):
+    """In place: g += wd*p; sum += g*g; p -= lr * g / (sqrt(sum) + eps).
+
+    eps is 1e-8, not Adagrad's 1e-10: OptimRegime builds Adam(lr=0) first and re-wraps its
+    param_groups (utils/optim.py:29,143-146), so Adam's eps leaks [confirmed by
+    tests/golden/make_golden.py: 'effective Adagrad group'].  lr_decay = 0, initial accumulator 0.
+    Applied to EVERY row (dense gradients, model_config.sparse False).
+    """
+    dt = p.dtype
+    g = g + dt.type(weight_decay) * p
+    state_sum += g * g
+    std = np.sqrt(state_sum) + dt.type(eps)
+    p -= dt.type(lr) * (g / std)
+    return p, state_sum
+
+
+# ------------------------------------------------------------------------------------------------
+# filtered ranks                          openkge/dataset.py:423-453 (compute_metrics)
+# ------------------------------------------------------------------------------------------------
+def filtered_ranks(pred, filt, row_ptr, grp_ptr, ids):
+    """Per (row, answer group): true = max_{j in group} pred[row, j]; pred[filter] = -1e8;
+    rank = #(pred' > true) + (#(pred' == true)) // 2   (dataset.py:436-446).  int64, exact.
+
+    Groups are CSR-of-CSR: row b owns groups row_ptr[b]..row_ptr[b+1]; group g owns
+    ids[grp_ptr[g]..grp_ptr[g+1]] (candidate-relative ids, dataset.py:921-926).
+    """
+    pred = np.asarray(pred, dtype=np.float32)
+    ranks = np.zeros(len(grp_ptr) - 1, dtype=np.int64)
+    for b in range(pred.shape[0]):
+        masked = np.where(np.asarray(filt[b]).astype(bool), np.float32(-1e8), pred[b])
+        for g in range(row_ptr[b], row_ptr[b + 1]):
+            true = pred[b, ids[grp_ptr[g]:grp_ptr[g + 1]]].max()
+            gt = int((masked > true).sum())
+            eq = int((masked == true).sum())
+            ranks[g] = gt + eq // 2
+    return ranks
+
+
+def metrics_from_ranks(ranks, row_ptr):
+    """MetricResult averages of compute_metrics (dataset.py:447-452, utils/metrics.py:20-23):
+    each meter is a count-weighted running mean over rows -> equals the plain mean over groups."""
+    ranks = np.asarray(ranks, dtype=np.int64)
+    out = {"mrr": 0.0, "mr": 0.0, "h1": 0.0, "h3": 0.0, "h10": 0.0, "h50": 0.0}
+    n = len(ranks)
+    if n == 0:
+        return out, 0
+    out["mrr"] = float((1.0 / (ranks + 1).astype(np.float32)).astype(np.float64).sum() / n)
+    out["mr"] = float(ranks.sum() / n)
+    for k in (1, 3, 10, 50):
+        out[f"h{k}"] = float((ranks < k).sum() / n)
+    return out, n
+
+
+# ------------------------------------------------------------------------------------------------
+# counter-based dropout masks (this build's replacement for torch's bernoulli_, SURVEY.md 'hard
+# parts'): Philox4x32-10, key = seed, counter = (row, column/4, stream, step).  Integer work ->
+# the HIP kernels reproduce these masks bit for bit.
+# ------------------------------------------------------------------------------------------------
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 (Salmon et al. 2011).  Inputs uint32 arrays (broadcastable)."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = _PHILOX_M0 * c0.astype(np.uint64)
+            p1 = _PHILOX_M1 * c2.astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32((int(k0) + int(_PHILOX_W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(_PHILOX_W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def dropout_threshold(p):
+    """keep  <=>  u32 >= threshold, threshold = floor(p * 2^32) clipped to [0, 2^32-1]."""
+    return np.uint32(min(max(int(float(p) * 4294967296.0), 0), 4294967295))
+
+
+def dropout_keep_mask(seed, stream, step, nrows, d, p, row_keys=None):
+    """keep[row, k] for k < d.  counter = (row_key, k >> 2, stream, step); word k & 3 of the output.
+
+    row_key defaults to the row's position in the list (candidate position / batch row).
+    """
+    rows = np.arange(nrows, dtype=np.uint32) if row_keys is None else np.asarray(row_keys, dtype=np.uint32)
+    nq = (d + 3) // 4
+    q = np.arange(nq, dtype=np.uint32)
+    k0 = np.uint32(int(seed) & 0xFFFFFFFF)
+    k1 = np.uint32((int(seed) >> 32) & 0xFFFFFFFF)
+    w = philox4x32_10(rows[:, None], q[None, :], np.uint32(stream), np.uint32(int(step) & 0xFFFFFFFF), k0, k1)
+    u = np.stack(w, axis=-1).reshape(len(rows), nq * 4)[:, :d]
+    return u >= dropout_threshold(p)

@@ -1,0 +1,363 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the hot path by running the REFERENCE itself (CPU, this container only).
+
+Run (never on the GPU box -- /root/reference does not exist there):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference \
+        python3 -B /root/repo/tests/golden/make_golden.py
+
+The script imports the unmodified reference (openkge.model / openkge.trainer / openkge.dataset /
+utils.optim), drives the classes on the hot path with small seeded inputs and stores inputs and
+expected outputs as .npz fixtures next to this file.  Fixtures are DATA only (ids, tables, masks,
+scores, losses, gradients, updated weights, ranks); no reference source is copied.
+
+Vectors:
+  g1_scores_*     sp_prefix_score / po_prefix_score, ComplEx + DistMult, dropout 0
+  g2_loss_*       AddLossModule forward + (loss/normalizer).backward(): loss, all_outputs, dE, dR
+                  (bce, bce + label smoothing, kl, one direction None, batch-shared candidates,
+                  input_dropout 0.4 with the Bernoulli masks captured)
+  g3_adagrad_*    three optimisation steps through utils.optim.OptimRegime (Adagrad, leaked eps)
+  g5_ranks_*      OneToNMentionRelationDataset.compute_metrics (known answer + ties + mention groups)
+  g7_traj_*       20 training steps, fixed batches -> loss curve and final tables
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+assert os.path.isdir("/root/reference"), "golden vectors can only be generated where the reference is mounted"
+if "/root/reference" not in sys.path:
+    sys.path.insert(0, "/root/reference")
+
+from openkge.dataset import EntityRelationDatasetMeta, OneToNMentionRelationDataset  # noqa: E402
+from openkge.model import Models  # noqa: E402
+from openkge.trainer import AddLossModule  # noqa: E402
+from utils.optim import OptimRegime  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+def meta(n_ent, n_rel):
+    return EntityRelationDatasetMeta(
+        entity_id_count_map={}, relation_id_count_map={}, entity_token_id_count_map={},
+        relation_token_id_count_map={}, entity_id_to_tokens_map={}, relation_id_to_tokens_map={},
+        entities_size=n_ent, relations_size=n_rel, min_entities_size=2, min_relations_size=2,
+        entity_tokens_size=4, relation_tokens_size=4, max_length=1,
+    )
+
+
+def make_model(name, n_ent, n_rel, d, seed, input_dropout=0.0, init_std=0.1):
+    torch.manual_seed(seed)
+    m = getattr(Models, name)(entity_slot_size=d, input_dropout=input_dropout, init_std=init_std,
+                              sparse=False, train_data=meta(n_ent, n_rel))
+    return m
+
+
+def rand_ids(rng, lo, hi, n):
+    return torch.from_numpy(rng.integers(lo, hi, size=(n, 1)).astype(np.int32))
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", path, {k: (v.shape if hasattr(v, "shape") else v) for k, v in kw.items()})
+
+
+# ----------------------------------------------------------------------------------------------
+# G1: prefix scores
+# ----------------------------------------------------------------------------------------------
+def g1():
+    for mname, tag in (("LookupComplexRelationModel", "complex"), ("LookupDistmultRelationModel", "distmult")):
+        for (n_ent, n_rel, d, b, case) in ((66, 10, 16, 8, "tiny"), (301, 17, 200, 24, "d200"), (130, 9, 36, 5, "odd")):
+            rng = np.random.default_rng(1000 + d)
+            m = make_model(mname, n_ent, n_rel, d, seed=11 + d)
+            m.eval()
+            subj, rel_sp = rand_ids(rng, 2, n_ent, b), rand_ids(rng, 2, n_rel, b)
+            rel_po, obj = rand_ids(rng, 2, n_rel, b), rand_ids(rng, 2, n_ent, b)
+            cand = torch.from_numpy(rng.permutation(np.arange(2, n_ent))[: max(7, (n_ent - 2) // 2)].astype(np.int32))
+            with torch.no_grad():
+                sp_all = m.sp_prefix_score(subj, rel_sp)                 # all objects (ids 2..)
+                po_all = m.po_prefix_score(rel_po, obj)                  # all subjects
+                pre = m.precompute_batch_shared_inputs(cand.view(-1))
+                sp_c = m.sp_prefix_score(subj, rel_sp, pre)
+                po_c = m.po_prefix_score(rel_po, obj, pre)
+            save(f"g1_scores_{tag}_{case}",
+                 E=npy(m.entity_embedding.weight), R=npy(m.relation_embedding.weight),
+                 subj=npy(subj), rel_sp=npy(rel_sp), rel_po=npy(rel_po), obj=npy(obj), cand=npy(cand),
+                 sp_all=npy(sp_all), po_all=npy(po_all), sp_cand=npy(sp_c), po_cand=npy(po_c))
+
+
+# ----------------------------------------------------------------------------------------------
+# G2: loss + gradients through AddLossModule
+# ----------------------------------------------------------------------------------------------
+def dense_labels(rng, B, N, max_pos=4):
+    y = np.zeros((B, N), dtype=np.float32)
+    for b in range(B):
+        k = int(rng.integers(1, max_pos + 1))
+        y[b, rng.choice(N, size=k, replace=False)] = 1.0
+    return y
+
+
+def run_loss(mname, n_ent, n_rel, d, b_po, b_sp, loss_kind, smoothing, cand_mode, seed, input_dropout=0.0):
+    rng = np.random.default_rng(seed)
+    m = make_model(mname, n_ent, n_rel, d, seed=seed, input_dropout=input_dropout)
+    m.train()
+    if cand_mode == "all":
+        cand = torch.arange(n_ent)[2:].int().unsqueeze(1)
+    else:
+        ids = rng.permutation(np.arange(2, n_ent))[: int(cand_mode)]
+        cand = torch.from_numpy(ids.astype(np.int32)).unsqueeze(1)
+    N = cand.shape[0]
+    inputs = []
+    po = sp = None
+    if b_po > 0:
+        po = (rand_ids(rng, 2, n_rel, b_po), rand_ids(rng, 2, n_ent, b_po))
+    if b_sp > 0:
+        sp = (rand_ids(rng, 2, n_ent, b_sp), rand_ids(rng, 2, n_rel, b_sp))
+    inputs = [po, sp]
+    B = b_po + b_sp
+    y = dense_labels(rng, B, N)
+    labels = torch.from_numpy(y.copy())
+    if loss_kind == "bce":
+        loss = torch.nn.BCEWithLogitsLoss(reduction="sum")
+    else:
+        loss = torch.nn.KLDivLoss(reduction="sum")
+    mod = AddLossModule(m, loss, bce_label_smoothing=smoothing)
+    mod.train()
+    masks = {}
+    if input_dropout > 0:
+        # Capture the Bernoulli keep-masks the reference is about to draw: same generator state, same op
+        # sequence (candidates, then obj rows of po, then subj rows of sp; relation dropout is 0).
+        st = torch.get_rng_state()
+        torch.manual_seed(seed + 77)
+        masks["mask_cand"] = (torch.nn.functional.dropout(torch.ones(N, d), p=input_dropout, training=True) > 0)
+        if b_po > 0:
+            masks["mask_po_ent"] = (torch.nn.functional.dropout(torch.ones(b_po, d), p=input_dropout, training=True) > 0)
+        if b_sp > 0:
+            masks["mask_sp_ent"] = (torch.nn.functional.dropout(torch.ones(b_sp, d), p=input_dropout, training=True) > 0)
+        torch.set_rng_state(st)
+        torch.manual_seed(seed + 77)
+    out_loss, hook, outputs = mod(inputs=inputs, labels=labels, use_batch_shared_entities=(cand_mode != "all"),
+                                  batch_shared_entities=cand, epoch=1,
+                                  input_style_triple_or_prefix="right_and_left_prefix")
+    assert hook is None
+    normalizer = float(B * N)
+    (out_loss.sum() / normalizer).backward()
+    kw = dict(E=npy(m.entity_embedding.weight), R=npy(m.relation_embedding.weight),
+              cand=npy(cand), labels=y, loss=np.float64(out_loss.item()), outputs=npy(outputs),
+              dE=npy(m.entity_embedding.weight.grad), dR=npy(m.relation_embedding.weight.grad),
+              normalizer=np.float64(normalizer), smoothing=np.float64(smoothing),
+              input_dropout=np.float64(input_dropout))
+    if po is not None:
+        kw.update(po_rel=npy(po[0]), po_obj=npy(po[1]))
+    if sp is not None:
+        kw.update(sp_subj=npy(sp[0]), sp_rel=npy(sp[1]))
+    for k, v in masks.items():
+        kw[k] = npy(v).astype(np.uint8)
+    return kw
+
+
+def g2():
+    C, D = "LookupComplexRelationModel", "LookupDistmultRelationModel"
+    cases = [
+        # name, model, n_ent, n_rel, d, b_po, b_sp, loss, smoothing, cand, seed, dropout
+        ("complex_bce_all", C, 66, 10, 16, 6, 7, "bce", 0.0, "all", 21, 0.0),
+        ("complex_bce_smooth_all", C, 66, 10, 16, 6, 7, "bce", 0.1, "all", 22, 0.0),
+        ("complex_kl_all", C, 66, 10, 16, 6, 7, "kl", 0.0, "all", 23, 0.0),
+        ("complex_bce_po_only", C, 66, 10, 16, 9, 0, "bce", 0.0, "all", 24, 0.0),
+        ("complex_bce_sp_only", C, 66, 10, 16, 0, 9, "bce", 0.0, "all", 25, 0.0),
+        ("complex_bce_shared", C, 150, 12, 24, 10, 11, "bce", 0.0, "70", 26, 0.0),
+        ("complex_kl_shared", C, 150, 12, 24, 10, 11, "kl", 0.0, "70", 27, 0.0),
+        ("complex_bce_dropout_all", C, 66, 10, 16, 6, 7, "bce", 0.0, "all", 28, 0.4),
+        ("complex_bce_d200", C, 400, 20, 200, 40, 33, "bce", 0.0, "all", 29, 0.0),
+        ("complex_bce_d200_dropout", C, 400, 20, 200, 40, 33, "bce", 0.0, "all", 30, 0.4),
+        ("distmult_bce_all", D, 66, 10, 16, 6, 7, "bce", 0.0, "all", 31, 0.0),
+        ("distmult_kl_all", D, 66, 10, 16, 6, 7, "kl", 0.0, "all", 32, 0.0),
+        ("distmult_bce_shared_d64", D, 300, 12, 64, 20, 21, "bce", 0.0, "128", 33, 0.0),
+        ("distmult_bce_dropout_shared", D, 300, 12, 64, 20, 21, "bce", 0.0, "128", 34, 0.4),
+    ]
+    for (name, mname, n_ent, n_rel, d, b_po, b_sp, lk, sm, cm, seed, dp) in cases:
+        kw = run_loss(mname, n_ent, n_rel, d, b_po, b_sp, lk, sm, cm, seed, dp)
+        kw["loss_kind"] = np.array(lk)
+        kw["model"] = np.array("complex" if mname == C else "distmult")
+        save("g2_loss_" + name, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# G3: Adagrad through OptimRegime (eps leaked from the Adam shell)
+# ----------------------------------------------------------------------------------------------
+def g3():
+    for mname, tag in (("LookupComplexRelationModel", "complex"), ("LookupDistmultRelationModel", "distmult")):
+        n_ent, n_rel, d, b = 80, 9, 20, 12
+        seed = 41
+        rng = np.random.default_rng(seed)
+        m = make_model(mname, n_ent, n_rel, d, seed=seed)
+        m.train()
+        args = {"optimization_config": {"optimizer": "Adagrad", "epoch": 0, "lr": 0.3, "weight_decay": 1.0e-10},
+                "lr_scheduler_config": None}
+        opts = OptimRegime.setup_optimizer_regime(args=args, model=m)
+        mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+        mod.train()
+        E0, R0 = npy(m.entity_embedding.weight).copy(), npy(m.relation_embedding.weight).copy()
+        cand = torch.arange(n_ent)[2:].int().unsqueeze(1)
+        N = cand.shape[0]
+        steps = []
+        group_info = None
+        for step in range(3):
+            po = (rand_ids(rng, 2, n_rel, b), rand_ids(rng, 2, n_ent, b))
+            sp = (rand_ids(rng, 2, n_ent, b), rand_ids(rng, 2, n_rel, b))
+            y = dense_labels(rng, 2 * b, N)
+            for o in opts:
+                o.update(1, step + 1)
+            for o in opts:
+                o.zero_grad()
+            loss, _, _ = mod(inputs=[po, sp], labels=torch.from_numpy(y.copy()), use_batch_shared_entities=False,
+                             batch_shared_entities=cand, epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+            (loss.sum() / float(2 * b * N)).backward()
+            for o in opts:
+                o.step()
+            g = opts[0].optimizer.param_groups[0]
+            group_info = {k: g[k] for k in ("lr", "eps", "weight_decay", "lr_decay", "initial_accumulator_value")}
+            st = opts[0].optimizer.state
+            steps.append(dict(po_rel=npy(po[0]), po_obj=npy(po[1]), sp_subj=npy(sp[0]), sp_rel=npy(sp[1]), labels=y,
+                              loss=np.float64(loss.item()),
+                              E=npy(m.entity_embedding.weight).copy(), R=npy(m.relation_embedding.weight).copy(),
+                              sumE=npy(st[m.entity_embedding.weight]["sum"]).copy(),
+                              sumR=npy(st[m.relation_embedding.weight]["sum"]).copy()))
+        print("effective Adagrad group:", group_info, type(opts[0].optimizer).__name__)
+        kw = dict(E0=E0, R0=R0, cand=npy(cand), nsteps=np.int64(3))
+        for k, v in group_info.items():
+            kw["opt_" + k] = np.float64(v)
+        for i, s in enumerate(steps):
+            for k, v in s.items():
+                kw[f"s{i}_{k}"] = v
+        save(f"g3_adagrad_{tag}", **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# G5: filtered ranks
+# ----------------------------------------------------------------------------------------------
+def pack_groups(label_ids):
+    """list[B] of list[G_b] of int tensors -> (row_ptr[B+1], grp_ptr[G+1], ids[M])"""
+    row_ptr, grp_ptr, ids = [0], [0], []
+    for groups in label_ids:
+        for g in groups:
+            ids.extend(int(x) for x in g.tolist())
+            grp_ptr.append(len(ids))
+        row_ptr.append(len(grp_ptr) - 1)
+    return np.asarray(row_ptr, np.int64), np.asarray(grp_ptr, np.int64), np.asarray(ids, np.int32)
+
+
+def per_group_ranks(filter_mask, label_ids, predictions):
+    """The rank rule of compute_metrics, evaluated group by group with the reference's own tensor ops
+    (masked_fill_, <, ==, sum, //) so the integer ranks themselves can be stored (the reference only
+    returns their meters)."""
+    ranks = []
+    for f, groups, p in zip(filter_mask, label_ids, predictions):
+        true = torch.Tensor([p[g.long()].max(0)[0] for g in groups])
+        rep = p.unsqueeze(0).repeat(len(groups), 1)
+        rep.masked_fill_(f.unsqueeze(0).repeat(len(groups), 1), -1e8)
+        fp = (true.view(len(groups), -1) < rep).long().sum(1)
+        eq = (true.view(len(groups), -1) == rep).long().sum(1)
+        ranks.extend((fp + eq // 2).tolist())
+    return np.asarray(ranks, np.int64)
+
+
+def g5():
+    # known answer
+    pred = torch.tensor([[0.5, 0.9, 0.9, 0.2, 0.3, 0.9, 0.7, 5.0]])
+    filt = torch.zeros(1, 8, dtype=torch.bool)
+    filt[0, [1, 4, 6, 7]] = True
+    lids = [[torch.IntTensor([1]), torch.IntTensor([4, 6])]]
+    res = OneToNMentionRelationDataset.compute_metrics(filt, lids, pred)
+    rp, gp, ids = pack_groups(lids)
+    save("g5_ranks_known", pred=npy(pred), filt=npy(filt).astype(np.uint8), row_ptr=rp, grp_ptr=gp, ids=ids,
+         ranks=per_group_ranks(filt, lids, pred),
+         **{"m_" + k: np.float64(v.avg) for k, v in res.items()},
+         **{"c_" + k: np.float64(v.count) for k, v in res.items()})
+    # random with forced ties and multi-mention groups
+    for case, (B, N, seed) in {"rand_small": (9, 50, 5), "rand_wide": (6, 1000, 6), "rand_ties": (12, 200, 7)}.items():
+        rng = np.random.default_rng(seed)
+        p = rng.standard_normal((B, N)).astype(np.float32)
+        if case == "rand_ties":
+            p = np.round(p * 2) / 2  # many exact ties
+        filt = np.zeros((B, N), dtype=bool)
+        lids = []
+        for b in range(B):
+            ng = int(rng.integers(1, 5))
+            groups = []
+            for _ in range(ng):
+                sz = int(rng.integers(1, 4))
+                g = rng.choice(N, size=sz, replace=False)
+                groups.append(torch.IntTensor(g.astype(np.int32)))
+                filt[b, g] = True
+            extra = rng.choice(N, size=int(rng.integers(0, 6)), replace=False)  # answers from other splits
+            filt[b, extra] = True
+            lids.append(groups)
+        pt, ft = torch.from_numpy(p), torch.from_numpy(filt)
+        res = OneToNMentionRelationDataset.compute_metrics(ft, lids, pt)
+        rp, gp, ids = pack_groups(lids)
+        save("g5_ranks_" + case, pred=p, filt=filt.astype(np.uint8), row_ptr=rp, grp_ptr=gp, ids=ids,
+             ranks=per_group_ranks(ft, lids, pt),
+             **{"m_" + k: np.float64(v.avg) for k, v in res.items()},
+             **{"c_" + k: np.float64(v.count) for k, v in res.items()})
+
+
+# ----------------------------------------------------------------------------------------------
+# G7: short trajectory
+# ----------------------------------------------------------------------------------------------
+def g7():
+    mname = "LookupComplexRelationModel"
+    n_ent, n_rel, d, b, nsteps = 120, 11, 32, 16, 20
+    seed = 51
+    rng = np.random.default_rng(seed)
+    m = make_model(mname, n_ent, n_rel, d, seed=seed)
+    m.train()
+    args = {"optimization_config": {"optimizer": "Adagrad", "epoch": 0, "lr": 0.3, "weight_decay": 1.0e-10},
+            "lr_scheduler_config": None}
+    opts = OptimRegime.setup_optimizer_regime(args=args, model=m)
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+    mod.train()
+    E0, R0 = npy(m.entity_embedding.weight).copy(), npy(m.relation_embedding.weight).copy()
+    cand = torch.arange(n_ent)[2:].int().unsqueeze(1)
+    N = cand.shape[0]
+    # four fixed batches cycled
+    batches = []
+    for _ in range(4):
+        batches.append((rand_ids(rng, 2, n_rel, b), rand_ids(rng, 2, n_ent, b), rand_ids(rng, 2, n_ent, b),
+                        rand_ids(rng, 2, n_rel, b), dense_labels(rng, 2 * b, N)))
+    losses = []
+    for step in range(nsteps):
+        po_rel, po_obj, sp_subj, sp_rel, y = batches[step % 4]
+        for o in opts:
+            o.update(1, step + 1)
+            o.zero_grad()
+        loss, _, _ = mod(inputs=[(po_rel, po_obj), (sp_subj, sp_rel)], labels=torch.from_numpy(y.copy()),
+                         use_batch_shared_entities=False, batch_shared_entities=cand, epoch=1,
+                         input_style_triple_or_prefix="right_and_left_prefix")
+        (loss.sum() / float(2 * b * N)).backward()
+        for o in opts:
+            o.step()
+        losses.append(loss.item() / float(2 * b * N))
+    kw = dict(E0=E0, R0=R0, cand=npy(cand), losses=np.asarray(losses, np.float64),
+              E=npy(m.entity_embedding.weight), R=npy(m.relation_embedding.weight), nsteps=np.int64(nsteps))
+    for i, (a, b_, c, e, y) in enumerate(batches):
+        kw.update({f"b{i}_po_rel": npy(a), f"b{i}_po_obj": npy(b_), f"b{i}_sp_subj": npy(c), f"b{i}_sp_rel": npy(e),
+                   f"b{i}_labels": y})
+    save("g7_traj_complex", **kw)
+
+
+if __name__ == "__main__":
+    g1()
+    g2()
+    g3()
+    g5()
+    g7()
+    print("torch", torch.__version__, "numpy", np.__version__)
