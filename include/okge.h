@@ -1,0 +1,164 @@
+/*
+ * okge.h -- C ABI of the MI355X-native open-KGE hot path (libokge_hip.so, gfx950).
+ *
+ * Drop-in boundary for the batched prefix-scoring training/evaluation loop of
+ * samuelbroscheit/open_knowledge_graph_embeddings.  The reference has no FFI on this path: it is a
+ * Python class protocol over ATen ops.  Each entry point below names the reference interface whose
+ * arithmetic it replaces (paths relative to the reference checkout); the Python host classes in
+ * open_knowledge_graph_embeddings_amd/ keep the reference's method names and call these through ctypes.
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes/strides, no torch types;
+ *   - every call enqueues on the HIP stream passed as `stream` (a hipStream_t cast to void*; NULL =
+ *     default stream) and returns without synchronising;
+ *   - return value: OKGE_OK (0) or a negative error code; okge_last_error() returns the message of
+ *     the last failing call on the calling thread;
+ *   - ids are int32 (reference: dataset.py:891,932), tables/scores/gradients fp32 row-major;
+ *   - batch rows are ordered po-rows first, then sp-rows (trainer.py:69-71,91); either may be empty.
+ */
+#ifndef OKGE_H
+#define OKGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OKGE_ABI_VERSION 1
+
+enum okge_status {
+    OKGE_OK = 0,
+    OKGE_ERR_INVALID = -1,      /* bad argument (shape, NULL pointer, unsupported size)            */
+    OKGE_ERR_UNSUPPORTED = -2,  /* configuration outside the fused path (e.g. slot size too large) */
+    OKGE_ERR_WORKSPACE = -3,    /* workspace too small; call okge_train_workspace_bytes()          */
+    OKGE_ERR_HIP = -4           /* a HIP runtime call or kernel launch failed                      */
+};
+
+enum okge_scorer { OKGE_COMPLEX = 0, OKGE_DISTMULT = 1 };   /* model.py:176-240 / :243-278 */
+enum okge_loss   { OKGE_LOSS_BCE = 0, OKGE_LOSS_KL = 1 };   /* trainer.py:93-106           */
+
+/* Dropout applied to gathered embedding rows (model.py:461-462, F.dropout in training mode).
+ * p == 0 disables it.  If `keep` is non-NULL it is an explicit keep-mask, uint8 [rows][d]
+ * (1 = keep) -- used for parity runs against masks captured from the reference; otherwise the mask
+ * is Philox4x32-10(key = seed, counter = (row position, column/4, stream, step)), word column&3,
+ * keep <=> word >= floor(p * 2^32).  Kept values are multiplied by 1/(1-p). */
+typedef struct okge_dropout {
+    float          p;
+    uint32_t       stream;
+    uint32_t       step;
+    uint32_t       _pad;
+    uint64_t       seed;
+    const uint8_t *keep;
+} okge_dropout;
+
+/* One batch of prefixes.  Replaces the `inputs` list AddLossModule.forward receives
+ * (trainer.py:48-71): [ (rel(b0,1), obj(b0,1)) | None , (subj(b1,1), rel(b1,1)) | None ]. */
+typedef struct okge_prefix_batch {
+    const int32_t *po_rel;  /* [n_po] relation ids of the (?, r, o) rows   */
+    const int32_t *po_obj;  /* [n_po] object entity ids                    */
+    const int32_t *sp_subj; /* [n_sp] subject entity ids of (s, r, ?) rows */
+    const int32_t *sp_rel;  /* [n_sp] relation ids                         */
+    int32_t        n_po;
+    int32_t        n_sp;
+    okge_dropout   drop_po_ent, drop_po_rel, drop_sp_ent, drop_sp_rel;
+} okge_prefix_batch;
+
+/* Candidate entity set shared by every row of the batch (trainer.py:75-87).
+ * ids == NULL means the contiguous range first_id .. first_id + n - 1 (1-vs-all: first_id = 2,
+ * model.py:512-523 `weight[min_entities_size:]`); otherwise ids[n] (batch-shared sample,
+ * model.py:76-77), which must not contain duplicates for the training entry point. */
+typedef struct okge_candidates {
+    const int32_t *ids;
+    int32_t        first_id;
+    int32_t        n;
+    okge_dropout   drop;
+} okge_candidates;
+
+/* Embedding tables: entity_embedding.weight (n_ent, d), relation_embedding.weight (n_rel, d)
+ * (model.py:390-391), contiguous fp32. */
+typedef struct okge_tables {
+    float  *E;
+    float  *R;
+    int32_t n_ent;
+    int32_t n_rel;
+    int32_t d;
+    int32_t scorer; /* enum okge_scorer */
+} okge_tables;
+
+/* Positive labels of the batch as coordinates (row in [0,B), column in [0,N) = candidate position),
+ * SORTED BY COLUMN (ties in any order).  Replaces the dense (B,N) fp32 label tensor the reference's
+ * collate function builds (dataset.py:885-932); labels are {0,1} there. */
+typedef struct okge_positives {
+    const int32_t *col;
+    const int32_t *row;
+    int32_t        nnz;
+} okge_positives;
+
+int         okge_abi_version(void);
+const char *okge_last_error(void);
+
+/* ---- scoring (evaluation and the API-compatible *_prefix_score methods) ---------------------------
+ * Replaces RelationScorer.po_prefix_score / sp_prefix_score -> _score(prefix=True)
+ * (model.py:52-74, ComplEx :198-229, DistMult :268-274) together with the embedder calls they make
+ * (model.py:455-510): gathers and (optionally) drops out the prefix rows, folds them into one query
+ * row each, and writes scores[B][ld_scores] = query . candidate for every candidate. */
+int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                        float *scores, int64_t ld_scores, void *workspace, size_t workspace_bytes,
+                        void *stream);
+
+/* ---- fused training step: forward + loss + backward ------------------------------------------------
+ * Replaces AddLossModule.forward (trainer.py:48-113) followed by
+ * `(loss.sum() / normalizer).backward()` (trainer.py:217-234) for
+ * scorer in {ComplEx, DistMult} x LookupSimpleRelationEmbedder x loss in {bce, kl}.
+ *   loss_out  : device double[1]; receives the SUMMED loss (what AddLossModule returns as `result`)
+ *   dE, dR    : dense gradient buffers (n_ent, d) / (n_rel, d); the step ACCUMULATES into them
+ *               (like autograd's .grad); they must be zero (or hold earlier accumulation) on entry
+ *   scores    : optional [B][ld_scores] output of all_outputs (NULL to skip -- training never needs it)
+ *   normalizer: the reference divides the loss by B*N before backward (dataset.py:935)
+ * No (B,N) label or score tensor is read; positives come as coordinates. */
+int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch,
+                                const okge_candidates *cand, const okge_positives *pos,
+                                int32_t loss_kind, float label_smoothing, double normalizer,
+                                double *loss_out, float *dE, float *dR,
+                                float *scores, int64_t ld_scores,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* Bytes of scratch okge_train_forward_backward / okge_score_prefixes need for a batch of B rows
+ * against N candidates with slot size d (0 on invalid arguments). */
+size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d);
+
+/* ---- dense Adagrad ----------------------------------------------------------------------------------
+ * Replaces torch.optim.Adagrad.step as configured by OptimRegime (utils/optim.py:29,139-160):
+ * g += wd*p; sum += g*g; p -= lr * g / (sqrt(sum) + eps), over all n elements.  If zero_grad != 0 the
+ * gradient buffer is cleared in the same sweep (replaces optimizer.zero_grad(), trainer.py:229-244). */
+int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr, float weight_decay,
+                      float eps, int32_t zero_grad, void *stream);
+
+/* ---- filtered ranks ---------------------------------------------------------------------------------
+ * Replaces OneToNMentionRelationDataset.compute_metrics' rank rule (dataset.py:423-446):
+ * for row b and each of its answer groups g: true = max_{j in g} scores[b][j];
+ * scores'[b][j] = filter(b,j) ? -1e8 : scores[b][j];
+ * ranks[g] = #(scores' > true) + (#(scores' == true)) / 2.
+ * Filters are CSR (filt_ptr[B+1], filt_col) over candidate positions -- the reference's dense bool
+ * filter mask (dataset.py:927) as coordinates; groups are CSR of CSR: row b owns groups
+ * row_ptr[b]..row_ptr[b+1], group g owns ids[grp_ptr[g]..grp_ptr[g+1]].  ranks: int64[n_groups]. */
+int okge_filtered_ranks(const float *scores, int64_t ld_scores, int32_t B, int32_t N,
+                        const int64_t *filt_ptr, const int32_t *filt_col,
+                        const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
+                        int64_t *ranks, void *stream);
+
+/* ---- measurement ------------------------------------------------------------------------------------
+ * When enabled, every kernel launch of the calls above is bracketed by HIP events on its stream.
+ * okge_timing_collect synchronises the events and returns per-kernel totals since the last reset:
+ * names[i] (static strings), total_ms[i], launches[i]; returns the number of kernels (<= cap). */
+int okge_timing_enable(int32_t on);
+int okge_timing_reset(void);
+int okge_timing_collect(const char **names, double *total_ms, int64_t *launches, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKGE_H */

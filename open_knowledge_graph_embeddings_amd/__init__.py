@@ -1,0 +1,10 @@
+"""MI355X-native drop-in for the batched prefix-scoring training path of open_knowledge_graph_embeddings.
+
+Host code mirrors the reference's plugin interface (``model.Models``, ``RelationScorer`` /
+``RelationEmbedder`` method names, ``trainer.AddLossModule``); the arithmetic runs in hand-written
+HIP kernels for gfx950 behind the C ABI declared in ``include/okge.h``.
+"""
+from . import _native  # noqa: F401
+from ._native import OkgeError, build_native  # noqa: F401
+
+__all__ = ["OkgeError", "build_native"]

@@ -1,0 +1,133 @@
+"""ctypes binding of libokge_hip.so (include/okge.h).  Thin: structs, argtypes, error -> exception.
+
+The library is built in-tree by ``build_native()`` (hipcc --offload-arch=gfx950) and there is NO CPU
+fallback: if it cannot be loaded, or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_uint8, c_uint32, \
+    c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libokge_hip.so")
+SOURCES = ["okge_api.hip", "okge_train.hip", "okge_misc.hip"]
+HEADERS = ["okge_device.h", "okge_kernels.h", os.path.join("..", "..", "include", "okge.h")]
+
+OKGE_COMPLEX, OKGE_DISTMULT = 0, 1
+OKGE_LOSS_BCE, OKGE_LOSS_KL = 0, 1
+SCORERS = {"complex": OKGE_COMPLEX, "distmult": OKGE_DISTMULT}
+LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
+
+# every symbol include/okge.h declares
+EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
+           "okge_train_workspace_bytes", "okge_adagrad_step", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_timing_reset", "okge_timing_collect"]
+
+
+class OkgeError(RuntimeError):
+    pass
+
+
+class Dropout(Structure):
+    _fields_ = [("p", c_float), ("stream", c_uint32), ("step", c_uint32), ("_pad", c_uint32), ("seed", c_uint64),
+                ("keep", c_void_p)]
+
+
+class PrefixBatch(Structure):
+    _fields_ = [("po_rel", c_void_p), ("po_obj", c_void_p), ("sp_subj", c_void_p), ("sp_rel", c_void_p),
+                ("n_po", c_int32), ("n_sp", c_int32),
+                ("drop_po_ent", Dropout), ("drop_po_rel", Dropout), ("drop_sp_ent", Dropout), ("drop_sp_rel", Dropout)]
+
+
+class Candidates(Structure):
+    _fields_ = [("ids", c_void_p), ("first_id", c_int32), ("n", c_int32), ("drop", Dropout)]
+
+
+class Tables(Structure):
+    _fields_ = [("E", c_void_p), ("R", c_void_p), ("n_ent", c_int32), ("n_rel", c_int32), ("d", c_int32),
+                ("scorer", c_int32)]
+
+
+class Positives(Structure):
+    _fields_ = [("col", c_void_p), ("row", c_void_p), ("nnz", c_int32)]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_native(force=False, verbose=False):
+    """hipcc cross-compiles for gfx950 without a GPU (about 20 s)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """Load (never build implicitly on a box without hipcc) the C-ABI library; raise loudly if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise OkgeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.okge_abi_version.restype = c_int32
+    L.okge_last_error.restype = c_char_p
+    L.okge_train_workspace_bytes.restype = c_size_t
+    L.okge_train_workspace_bytes.argtypes = [c_int32, c_int32, c_int32]
+    L.okge_score_prefixes.restype = c_int32
+    L.okge_score_prefixes.argtypes = [POINTER(Tables), POINTER(PrefixBatch), POINTER(Candidates), c_void_p, c_int64,
+                                      c_void_p, c_size_t, c_void_p]
+    L.okge_train_forward_backward.restype = c_int32
+    L.okge_train_forward_backward.argtypes = [POINTER(Tables), POINTER(PrefixBatch), POINTER(Candidates),
+                                              POINTER(Positives), c_int32, c_float, c_double, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]
+    L.okge_adagrad_step.restype = c_int32
+    L.okge_adagrad_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int32, c_void_p]
+    L.okge_filtered_ranks.restype = c_int32
+    L.okge_filtered_ranks.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]
+    L.okge_timing_enable.restype = c_int32
+    L.okge_timing_enable.argtypes = [c_int32]
+    L.okge_timing_reset.restype = c_int32
+    L.okge_timing_collect.restype = c_int32
+    L.okge_timing_collect.argtypes = [POINTER(c_char_p), POINTER(c_double), POINTER(c_int64), c_int32]
+    if L.okge_abi_version() != 1:
+        raise OkgeError("libokge_hip.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().okge_last_error()
+        raise OkgeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def timing_collect():
+    """{kernel name: (total_ms, launches)} since the last reset."""
+    L = lib()
+    cap = 32
+    names = (c_char_p * cap)()
+    ms = (c_double * cap)()
+    cnt = (c_int64 * cap)()
+    n = L.okge_timing_collect(names, ms, cnt, cap)
+    return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+
+_ = (c_uint8,)

@@ -1,0 +1,398 @@
+// C ABI (include/okge.h) over the gfx950 kernels.  Host-side only: argument checking, workspace carving,
+// launch geometry, HIP-event timing.  No torch, no CPU fallback: every entry point either enqueues HIP
+// kernels or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/okge.h"
+#include "okge_kernels.h"
+
+using namespace okge;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return OKGE_ERR_HIP;
+}
+
+// ---- per-kernel HIP-event timing ----------------------------------------------------------------------
+struct TimedLaunch {
+    const char *name;
+    hipEvent_t  start, stop;
+};
+std::mutex               g_tmu;
+bool                     g_timing = false;
+std::vector<TimedLaunch> g_launches;
+std::vector<hipEvent_t>  g_event_pool;
+
+hipEvent_t get_event()
+{
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer {
+    hipStream_t st;
+    bool        on;
+    TimedLaunch t;
+    ScopedTimer(const char *name, hipStream_t s) : st(s), on(g_timing)
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_tmu);
+        t.name = name;
+        t.start = get_event();
+        t.stop = get_event();
+        (void)hipEventRecord(t.start, st);
+    }
+    ~ScopedTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(t.stop, st);
+        std::lock_guard<std::mutex> lk(g_tmu);
+        g_launches.push_back(t);
+    }
+};
+
+// ---- helpers ---------------------------------------------------------------------------------------------
+DropDev to_dev(const okge_dropout &d)
+{
+    DropDev r;
+    std::memset(&r, 0, sizeof(r));
+    r.scale = 1.f;
+    if (d.p > 0.f) {
+        r.enabled = 1;
+        r.keep = d.keep;
+        r.scale = 1.0f / (1.0f - d.p);
+        const double t = (double)d.p * 4294967296.0;
+        r.thr = t <= 0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+        r.k0 = (uint32_t)d.seed;
+        r.k1 = (uint32_t)(d.seed >> 32);
+        r.stream = d.stream;
+        r.step = d.step;
+    }
+    return r;
+}
+
+PrefixDev to_dev(const okge_prefix_batch &b)
+{
+    PrefixDev p;
+    p.po_rel = b.po_rel; p.po_obj = b.po_obj; p.sp_subj = b.sp_subj; p.sp_rel = b.sp_rel;
+    p.n_po = b.n_po; p.n_sp = b.n_sp;
+    p.drop_po_ent = to_dev(b.drop_po_ent); p.drop_po_rel = to_dev(b.drop_po_rel);
+    p.drop_sp_ent = to_dev(b.drop_sp_ent); p.drop_sp_rel = to_dev(b.drop_sp_rel);
+    return p;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Geometry {
+    int    B, N, d, Bpad, D16, KB, LDK, ldq, ldgt, tiles, b_split, b_per_block, nsplit;
+    size_t off_Q, off_GT, off_slab, off_loss, off_stats, off_lse, off_ysum, total;
+};
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
+bool make_geometry(int B, int N, int d, Geometry &g)
+{
+    if (B <= 0 || N <= 0 || d <= 0) return false;
+    g.B = B; g.N = N; g.d = d;
+    g.Bpad = (B + BC - 1) / BC * BC;
+    g.D16 = (d + 15) / 16 * 16;
+    g.KB = g.D16 / 16;
+    g.LDK = lds_ld(g.D16);
+    g.ldq = g.D16;
+    g.ldgt = g.Bpad;
+    g.tiles = (N + NT - 1) / NT;
+    const int bblks = g.Bpad / BC;
+    // fill the 256 CUs: if there are few candidate tiles, split the batch rows across blockIdx.y
+    int bs = 1;
+    if (g.tiles < 192) bs = std::min(bblks, (256 + g.tiles - 1) / g.tiles);
+    bs = std::max(1, env_int("OKGE_B_SPLIT", bs));
+    bs = std::min(bs, bblks);
+    g.b_per_block = (bblks + bs - 1) / bs * BC;
+    g.b_split = (g.Bpad + g.b_per_block - 1) / g.b_per_block;
+    // dQ kernel: (batch block, candidate range) workgroups, about two per CU
+    int ns = std::max(1, 512 / bblks);
+    ns = env_int("OKGE_DQ_SPLIT", ns);
+    ns = std::max(1, std::min(ns, g.tiles));
+    if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
+    g.nsplit = ns;
+    size_t off = 0;
+    g.off_Q = off;     off += align_up((size_t)g.Bpad * g.ldq * sizeof(float), 256);
+    g.off_GT = off;    off += align_up((size_t)N * g.ldgt * sizeof(float), 256);
+    g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
+    g.off_loss = off;  off += align_up((size_t)g.tiles * g.b_split * sizeof(double), 256);
+    g.off_stats = off; off += align_up((size_t)g.tiles * g.Bpad * 2 * sizeof(float), 256);
+    g.off_lse = off;   off += align_up((size_t)g.Bpad * sizeof(float), 256);
+    g.off_ysum = off;  off += align_up((size_t)g.Bpad * sizeof(float), 256);
+    g.total = off;
+    return true;
+}
+
+int check_common(const okge_tables *t, const okge_prefix_batch *b, const okge_candidates *c)
+{
+    if (!t || !b || !c) return fail(OKGE_ERR_INVALID, "null descriptor");
+    if (!t->E || !t->R) return fail(OKGE_ERR_INVALID, "null embedding table");
+    if (t->d <= 0 || t->n_ent <= 0 || t->n_rel <= 0) return fail(OKGE_ERR_INVALID, "bad table shape");
+    if (t->scorer != OKGE_COMPLEX && t->scorer != OKGE_DISTMULT) return fail(OKGE_ERR_INVALID, "unknown scorer");
+    if (t->scorer == OKGE_COMPLEX && (t->d & 1)) return fail(OKGE_ERR_INVALID, "ComplEx needs an even slot size");
+    if (t->d > 256)
+        return fail(OKGE_ERR_UNSUPPORTED, "slot size > 256 is not supported by the fused tile kernel yet");
+    if (b->n_po < 0 || b->n_sp < 0 || b->n_po + b->n_sp <= 0) return fail(OKGE_ERR_INVALID, "empty batch");
+    if (b->n_po > 0 && (!b->po_rel || !b->po_obj)) return fail(OKGE_ERR_INVALID, "null po ids");
+    if (b->n_sp > 0 && (!b->sp_subj || !b->sp_rel)) return fail(OKGE_ERR_INVALID, "null sp ids");
+    if (c->n <= 0) return fail(OKGE_ERR_INVALID, "no candidates");
+    if (!c->ids && (c->first_id < 0 || (int64_t)c->first_id + c->n > t->n_ent))
+        return fail(OKGE_ERR_INVALID, "candidate range outside the entity table");
+    return OKGE_OK;
+}
+
+void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, const okge_candidates *c, char *ws)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.E = t->E;
+    a.cand_ids = c->ids;
+    a.cand_first = c->first_id;
+    a.Q = reinterpret_cast<const float *>(ws + g.off_Q);
+    a.drop_c = to_dev(c->drop);
+    a.d = g.d; a.KB = g.KB; a.LDK = g.LDK; a.N = g.N; a.B = g.B; a.Bpad = g.Bpad; a.ldq = g.ldq; a.ldgt = g.ldgt;
+    a.b_per_block = g.b_per_block;
+}
+
+}  // namespace
+
+extern "C" {
+
+int okge_abi_version(void) { return OKGE_ABI_VERSION; }
+
+const char *okge_last_error(void) { return g_err.c_str(); }
+
+size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d)
+{
+    Geometry g;
+    if (!make_geometry(B, N, d, g)) return 0;
+    return g.total;
+}
+
+int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                        float *scores, int64_t ld_scores, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_common(t, batch, cand)) return rc;
+    if (!scores || ld_scores < cand->n) return fail(OKGE_ERR_INVALID, "bad scores buffer");
+    Geometry g;
+    make_geometry(batch->n_po + batch->n_sp, cand->n, t->d, g);
+    const size_t need = g.off_GT;   // only the query block
+    if (!workspace || workspace_bytes < need) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    const PrefixDev p = to_dev(*batch);
+    {
+        ScopedTimer tm("encode_queries", st);
+        hipError_t e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q),
+                                             g.ldq, g.Bpad, st);
+        if (e != hipSuccess) return fail_hip(e, "encode_queries");
+    }
+    FusedArgs a;
+    fill_fused_common(a, g, t, cand, ws);
+    a.X = scores;
+    a.ldx = ld_scores;
+    a.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
+    a.b_per_block = g.Bpad;     // rows are independent in score mode, but one pass per tile keeps C resident
+    {
+        ScopedTimer tm("fused_tile_score", st);
+        hipError_t e = launch_fused(MODE_SCORE, a, g.tiles, 1, st);
+        if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
+    }
+    return OKGE_OK;
+}
+
+int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                                const okge_positives *pos, int32_t loss_kind, float label_smoothing,
+                                double normalizer, double *loss_out, float *dE, float *dR, float *scores,
+                                int64_t ld_scores, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_common(t, batch, cand)) return rc;
+    if (!pos || pos->nnz < 0 || (pos->nnz > 0 && (!pos->col || !pos->row)))
+        return fail(OKGE_ERR_INVALID, "bad positives");
+    if (loss_kind != OKGE_LOSS_BCE && loss_kind != OKGE_LOSS_KL) return fail(OKGE_ERR_INVALID, "unknown loss");
+    if (!loss_out || !dE || !dR) return fail(OKGE_ERR_INVALID, "null output");
+    if (!(normalizer > 0)) return fail(OKGE_ERR_INVALID, "normalizer must be positive");
+    if (scores && ld_scores < cand->n) return fail(OKGE_ERR_INVALID, "bad scores buffer");
+    Geometry g;
+    make_geometry(batch->n_po + batch->n_sp, cand->n, t->d, g);
+    if (!workspace || workspace_bytes < g.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    const PrefixDev p = to_dev(*batch);
+    hipError_t e;
+    {
+        ScopedTimer tm("encode_queries", st);
+        e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
+                                  g.Bpad, st);
+        if (e != hipSuccess) return fail_hip(e, "encode_queries");
+    }
+    FusedArgs a;
+    fill_fused_common(a, g, t, cand, ws);
+    a.pos_col = pos->col; a.pos_row = pos->row; a.nnz = pos->nnz;
+    a.GT = reinterpret_cast<float *>(ws + g.off_GT);
+    a.dE = dE;
+    a.loss_partial = reinterpret_cast<double *>(ws + g.off_loss);
+    a.loss_kind = loss_kind;
+    a.inv_norm = (float)(1.0 / normalizer);
+    // label smoothing (trainer.py:103-105): y <- (y + 1/N) * (1 - eps), bce branch only
+    a.y_pos = 1.f; a.y_neg = 0.f;
+    if (loss_kind == OKGE_LOSS_BCE && label_smoothing > 0.f) {
+        const float invn = 1.0f / (float)cand->n;
+        a.y_pos = (1.0f + invn) * (1.0f - label_smoothing);
+        a.y_neg = (0.0f + invn) * (1.0f - label_smoothing);
+    }
+    if (scores) {
+        FusedArgs s = a;
+        s.X = scores; s.ldx = ld_scores;
+        s.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
+        s.b_per_block = g.Bpad;
+        ScopedTimer tm("fused_tile_score", st);
+        e = launch_fused(MODE_SCORE, s, g.tiles, 1, st);
+        if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
+    }
+    if (loss_kind == OKGE_LOSS_KL) {
+        FusedArgs s = a;
+        s.stats = reinterpret_cast<float *>(ws + g.off_stats);
+        s.b_per_block = g.Bpad;
+        {
+            ScopedTimer tm("fused_tile_stats", st);
+            e = launch_fused(MODE_STATS, s, g.tiles, 1, st);
+            if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
+        }
+        ScopedTimer tm("kl_row_stats", st);
+        e = launch_kl_row_stats(s.stats, g.tiles, g.B, g.Bpad, pos->row, pos->nnz,
+                                reinterpret_cast<float *>(ws + g.off_lse), reinterpret_cast<float *>(ws + g.off_ysum), st);
+        if (e != hipSuccess) return fail_hip(e, "kl_row_stats");
+        a.row_lse = reinterpret_cast<const float *>(ws + g.off_lse);
+        a.row_ysum = reinterpret_cast<const float *>(ws + g.off_ysum);
+    }
+    {
+        ScopedTimer tm("fused_tile_train", st);
+        e = launch_fused(MODE_TRAIN, a, g.tiles, g.b_split, st);
+        if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
+    }
+    DqArgs q;
+    std::memset(&q, 0, sizeof(q));
+    q.E = t->E; q.cand_ids = cand->ids; q.cand_first = cand->first_id; q.GT = a.GT;
+    q.slab = reinterpret_cast<float *>(ws + g.off_slab);
+    q.drop_c = a.drop_c;
+    q.d = g.d; q.KB = g.KB; q.LDK = g.LDK; q.N = g.N; q.Bpad = g.Bpad; q.ldq = g.ldq; q.ldgt = g.ldgt;
+    q.nsplit = g.nsplit;
+    {
+        ScopedTimer tm("dq", st);
+        e = launch_dq(q, (g.Bpad / BC) * g.nsplit, st);
+        if (e != hipSuccess) return fail_hip(e, "dq_kernel");
+    }
+    {
+        ScopedTimer tm("prefix_backward", st);
+        e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, dE, dR, st);
+        if (e != hipSuccess) return fail_hip(e, "prefix_backward");
+    }
+    {
+        ScopedTimer tm("loss_reduce", st);
+        e = launch_loss_reduce(a.loss_partial, g.tiles * g.b_split, loss_out, st);
+        if (e != hipSuccess) return fail_hip(e, "loss_reduce");
+    }
+    return OKGE_OK;
+}
+
+int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr, float weight_decay, float eps,
+                      int32_t zero_grad, void *stream)
+{
+    if (!p || !g || !state_sum || n < 0) return fail(OKGE_ERR_INVALID, "bad adagrad arguments");
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(state_sum)) % 16)
+        return fail(OKGE_ERR_INVALID, "adagrad buffers must be 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("adagrad", st);
+    hipError_t e = launch_adagrad(p, g, state_sum, n, lr, weight_decay, eps, zero_grad, st);
+    if (e != hipSuccess) return fail_hip(e, "adagrad");
+    return OKGE_OK;
+}
+
+int okge_filtered_ranks(const float *scores, int64_t ld_scores, int32_t B, int32_t N, const int64_t *filt_ptr,
+                        const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
+                        int64_t *ranks, void *stream)
+{
+    if (!scores || !filt_ptr || !row_ptr || !grp_ptr || !ids || !ranks || B <= 0 || N <= 0 || ld_scores < N)
+        return fail(OKGE_ERR_INVALID, "bad rank arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("filtered_ranks", st);
+    hipError_t e = launch_ranks(scores, ld_scores, B, N, filt_ptr, filt_col, row_ptr, grp_ptr, ids, ranks, st);
+    if (e != hipSuccess) return fail_hip(e, "ranks");
+    return OKGE_OK;
+}
+
+int okge_timing_enable(int32_t on)
+{
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_timing = on != 0;
+    return OKGE_OK;
+}
+
+int okge_timing_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (auto &t : g_launches) {
+        g_event_pool.push_back(t.start);
+        g_event_pool.push_back(t.stop);
+    }
+    g_launches.clear();
+    return OKGE_OK;
+}
+
+int okge_timing_collect(const char **names, double *total_ms, int64_t *launches, int32_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_tmu);
+    int n = 0;
+    for (auto &t : g_launches) {
+        if (hipEventSynchronize(t.stop) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.start, t.stop) != hipSuccess) continue;
+        int i = 0;
+        for (; i < n; ++i)
+            if (names[i] == t.name) break;
+        if (i == n) {
+            if (n >= cap) continue;
+            names[n] = t.name; total_ms[n] = 0; launches[n] = 0;
+            ++n;
+        }
+        total_ms[i] += ms;
+        launches[i] += 1;
+    }
+    return n;
+}
+
+}  // extern "C"

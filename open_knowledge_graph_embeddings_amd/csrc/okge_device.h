@@ -1,0 +1,102 @@
+// Device-side helpers shared by the gfx950 kernels of the open-KGE hot path.
+// gfx950 only: 64-wide wavefronts, v_mfma_f32_16x16x4_f32 (exact fp32 matrix FMA), 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace okge {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+// ---- dropout description as the kernels see it (host fills it from okge_dropout) -----------------
+struct DropDev {
+    const uint8_t *keep;   // explicit keep mask [rows][d] or nullptr
+    float          scale;  // 1/(1-p)   (1 when disabled)
+    uint32_t       thr;    // keep <=> philox word >= thr
+    uint32_t       k0, k1; // philox key = seed
+    uint32_t       stream, step;
+    int32_t        enabled;
+};
+
+// ---- Philox4x32-10 (Salmon et al. 2011), Random123 known-answer vectors in tests/ -------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// Multipliers (0 or 1/(1-p)) for the four columns 4*q4 .. 4*q4+3 of row `row_pos` of a gathered block
+// whose rows have `d` columns.  Columns >= d return 0.
+__device__ __forceinline__ float4 drop_mult4(const DropDev &dr, uint32_t row_pos, int q4, int d)
+{
+    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (!dr.enabled) return m;
+    if (dr.keep) {
+        const uint8_t *kp = dr.keep + (size_t)row_pos * d + 4 * q4;
+        const int k = 4 * q4;
+        m.x = (k + 0 < d && kp[0]) ? dr.scale : 0.f;
+        m.y = (k + 1 < d && kp[1]) ? dr.scale : 0.f;
+        m.z = (k + 2 < d && kp[2]) ? dr.scale : 0.f;
+        m.w = (k + 3 < d && kp[3]) ? dr.scale : 0.f;
+        return m;
+    }
+    const uint4 u = philox4x32_10(row_pos, (uint32_t)q4, dr.stream, dr.step, dr.k0, dr.k1);
+    m.x = u.x >= dr.thr ? dr.scale : 0.f;
+    m.y = u.y >= dr.thr ? dr.scale : 0.f;
+    m.z = u.z >= dr.thr ? dr.scale : 0.f;
+    m.w = u.w >= dr.thr ? dr.scale : 0.f;
+    return m;
+}
+
+__device__ __forceinline__ float drop_mult1(const DropDev &dr, uint32_t row_pos, int k, int d)
+{
+    if (!dr.enabled) return 1.f;
+    if (dr.keep) return dr.keep[(size_t)row_pos * d + k] ? dr.scale : 0.f;
+    const uint4 u = philox4x32_10(row_pos, (uint32_t)(k >> 2), dr.stream, dr.step, dr.k0, dr.k1);
+    const uint32_t w = (k & 3) == 0 ? u.x : (k & 3) == 1 ? u.y : (k & 3) == 2 ? u.z : u.w;
+    return w >= dr.thr ? dr.scale : 0.f;
+}
+
+// D(16x16) += A(16x4) * B(4x16), exact fp32.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
+// result register i of lane l is D[4*(l>>4)+i][l&15].
+__device__ __forceinline__ v4f mfma16(float a, float b, v4f c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Padded leading dimension (floats) of an LDS tile whose rows hold D16 floats: D16 + 4 = 4 * odd, so
+// (a) ds_read_b128 of 16 different rows at one column lands on 16 different 16-byte slots and
+// (b) ds_read_b32 of rows r and r+4 at 16 consecutive columns lands on disjoint bank halves.
+__host__ __device__ constexpr int lds_ld(int D16) { return D16 + 4; }
+
+}  // namespace okge

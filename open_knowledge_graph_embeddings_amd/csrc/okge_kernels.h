@@ -1,0 +1,69 @@
+// Kernel argument blocks and launcher prototypes shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "okge_device.h"
+
+namespace okge {
+
+constexpr int NT = 64;             // candidate rows per tile
+constexpr int BC = 64;             // batch rows per chunk
+constexpr int LDG = 68;            // leading dimension of the 64x64 G / X tile in LDS (4*odd)
+constexpr int FUSED_THREADS = 256; // 4 waves, one per SIMD
+
+enum { MODE_TRAIN = 0, MODE_SCORE = 1, MODE_STATS = 2 };
+enum { LOSS_BCE = 0, LOSS_KL = 1 };
+enum { SC_COMPLEX = 0, SC_DISTMULT = 1 };
+
+struct FusedArgs {
+    const float   *E;          // entity table (n_ent, d)
+    const int32_t *cand_ids;   // nullptr => cand_first + position
+    const float   *Q;          // folded queries [Bpad][ldq], zero padded to ldq >= D16
+    const int32_t *pos_col, *pos_row;
+    const float   *row_lse, *row_ysum;   // KL
+    float         *GT;         // [N][ldgt]  G^T
+    float         *dE;
+    double        *loss_partial;
+    float         *X;          // score mode
+    float         *stats;      // stats mode: float2 [tiles][Bpad]
+    int64_t        ldx;
+    DropDev        drop_c;
+    int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldgt, nnz, b_per_block, loss_kind, x_vec_ok;
+    float          y_pos, y_neg, inv_norm;
+};
+
+struct DqArgs {
+    const float   *E;
+    const int32_t *cand_ids;
+    const float   *GT;
+    float         *slab;       // [nsplit][Bpad][ldq]
+    DropDev        drop_c;
+    int32_t        d, KB, LDK, cand_first, N, Bpad, ldq, ldgt, nsplit;
+};
+
+struct PrefixDev {
+    const int32_t *po_rel, *po_obj, *sp_subj, *sp_rel;
+    int32_t        n_po, n_sp;
+    DropDev        drop_po_ent, drop_po_rel, drop_sp_ent, drop_sp_rel;
+};
+
+size_t     fused_shmem_bytes(int LDK);
+size_t     dq_shmem_bytes(int LDK);
+hipError_t launch_fused(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
+hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st);
+
+hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
+                                 int ldq, int Bpad, hipStream_t st);
+hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
+                                  const float *slab, int nsplit, int Bpad, int ldq, float *dE, float *dR,
+                                  hipStream_t st);
+hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
+hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, const int32_t *pos_row, int nnz,
+                               float *row_lse, float *row_ysum, hipStream_t st);
+hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, float wd, float eps, int zero_grad,
+                          hipStream_t st);
+hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
+                        const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
+                        int64_t *ranks, hipStream_t st);
+
+}  // namespace okge

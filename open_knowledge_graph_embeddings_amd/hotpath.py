@@ -1,0 +1,216 @@
+"""Host driver of the HIP hot path: torch tensors are containers (device memory + stream), all arithmetic
+happens in libokge_hip.so through the C ABI of include/okge.h.
+
+Reference call sites this module stands in for (paths relative to the reference checkout):
+  AddLossModule.forward + backward    openkge/trainer.py:48-113, :217-234   -> HotPath.forward_backward
+  *_prefix_score / _score             openkge/model.py:52-74, :198-229, :268-274 -> HotPath.score
+  optimizer.step / zero_grad          utils/optim.py:139-160, trainer.py:229-244 -> HotPath.adagrad
+  compute_metrics rank rule           openkge/dataset.py:423-446            -> HotPath.filtered_ranks
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import _native as N
+
+
+@dataclass
+class DropoutSpec:
+    """Dropout on gathered rows (model.py:461-462).  `keep` (uint8 [rows, d], device) overrides the
+    counter-based Philox mask -- used to replay masks captured from the reference."""
+    p: float = 0.0
+    seed: int = 0
+    stream: int = 0
+    step: int = 0
+    keep: Optional[torch.Tensor] = None
+
+    def c(self) -> N.Dropout:
+        d = N.Dropout()
+        d.p = float(self.p)
+        d.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
+        d.stream = int(self.stream) & 0xFFFFFFFF
+        d.step = int(self.step) & 0xFFFFFFFF
+        d.keep = self.keep.data_ptr() if (self.keep is not None and self.p > 0) else None
+        return d
+
+
+NO_DROP = DropoutSpec()
+
+# Philox stream ids: one per place the reference draws an independent Bernoulli mask
+STREAM_CAND, STREAM_PO_ENT, STREAM_PO_REL, STREAM_SP_ENT, STREAM_SP_REL = 0, 1, 2, 3, 4
+
+
+@dataclass
+class PrefixBatch:
+    """One batch in device memory: po rows (rel, obj) first, then sp rows (subj, rel); positives as
+    (row, col) coordinates sorted by col (col = position in the candidate list)."""
+    po_rel: Optional[torch.Tensor] = None   # int32 [n_po]
+    po_obj: Optional[torch.Tensor] = None
+    sp_subj: Optional[torch.Tensor] = None  # int32 [n_sp]
+    sp_rel: Optional[torch.Tensor] = None
+    pos_row: Optional[torch.Tensor] = None  # int32 [nnz]
+    pos_col: Optional[torch.Tensor] = None
+    cand_ids: Optional[torch.Tensor] = None  # int32 [N] or None for the range cand_first .. cand_first+N-1
+    cand_first: int = 2
+    n_cand: int = 0
+    drop_po_ent: DropoutSpec = field(default_factory=DropoutSpec)
+    drop_po_rel: DropoutSpec = field(default_factory=DropoutSpec)
+    drop_sp_ent: DropoutSpec = field(default_factory=DropoutSpec)
+    drop_sp_rel: DropoutSpec = field(default_factory=DropoutSpec)
+    drop_cand: DropoutSpec = field(default_factory=DropoutSpec)
+
+    @property
+    def n_po(self):
+        return 0 if self.po_rel is None else int(self.po_rel.numel())
+
+    @property
+    def n_sp(self):
+        return 0 if self.sp_subj is None else int(self.sp_subj.numel())
+
+    @property
+    def B(self):
+        return self.n_po + self.n_sp
+
+    @property
+    def nnz(self):
+        return 0 if self.pos_row is None else int(self.pos_row.numel())
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _i32(t, dev):
+    if t is None:
+        return None
+    t = t.reshape(-1)
+    if t.dtype != torch.int32 or t.device != dev or not t.is_contiguous():
+        t = t.to(device=dev, dtype=torch.int32).contiguous()
+    return t
+
+
+class HotPath:
+    """Owns the scratch workspace for one device and issues the C-ABI calls on torch's current stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise N.OkgeError("the open-KGE hot path runs on an MI355X (torch device 'cuda'); there is no CPU path")
+        self.lib = N.lib()
+        self._ws = None
+        self._ws_bytes = 0
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, B, n_cand, d):
+        need = int(self.lib.okge_train_workspace_bytes(B, n_cand, d))
+        if need == 0:
+            raise N.OkgeError(f"invalid problem size B={B} N={n_cand} d={d}")
+        if need > self._ws_bytes:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        return self._ws
+
+    def _tables(self, E, R, scorer):
+        for t in (E, R):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise N.OkgeError("embedding tables must be contiguous fp32 tensors on the engine's device")
+        t = N.Tables()
+        t.E, t.R = E.data_ptr(), R.data_ptr()
+        t.n_ent, t.n_rel, t.d = E.shape[0], R.shape[0], E.shape[1]
+        t.scorer = N.SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
+        return t
+
+    def _batch(self, b: PrefixBatch):
+        dev = self.device
+        keep = [_i32(b.po_rel, dev), _i32(b.po_obj, dev), _i32(b.sp_subj, dev), _i32(b.sp_rel, dev),
+                _i32(b.cand_ids, dev)]
+        pb = N.PrefixBatch()
+        pb.po_rel, pb.po_obj, pb.sp_subj, pb.sp_rel = (_ptr(x) for x in keep[:4])
+        pb.n_po, pb.n_sp = b.n_po, b.n_sp
+        pb.drop_po_ent, pb.drop_po_rel = b.drop_po_ent.c(), b.drop_po_rel.c()
+        pb.drop_sp_ent, pb.drop_sp_rel = b.drop_sp_ent.c(), b.drop_sp_rel.c()
+        c = N.Candidates()
+        c.ids = _ptr(keep[4])
+        c.first_id = int(b.cand_first)
+        c.n = int(b.n_cand if keep[4] is None else keep[4].numel())
+        c.drop = b.drop_cand.c()
+        return pb, c, keep
+
+    # -- entry points -------------------------------------------------------------------------------
+    def score(self, E, R, scorer, batch: PrefixBatch, out=None):
+        """(B, N) scores of every prefix against every candidate (eval / *_prefix_score)."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E, R, scorer)
+        B, n = batch.B, c.n
+        ws = self.workspace(B, n, t.d)
+        if out is None:
+            ld = (n + 3) // 4 * 4
+            out = torch.empty((B, ld), dtype=torch.float32, device=self.device)[:, :n]
+        N.check(self.lib.okge_score_prefixes(ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), out.data_ptr(),
+                                             out.stride(0), ws.data_ptr(), self._ws_bytes, self._stream()),
+                "okge_score_prefixes")
+        del keep
+        return out
+
+    def forward_backward(self, E, R, scorer, batch: PrefixBatch, dE, dR, loss="bce", label_smoothing=0.0,
+                         normalizer=None, loss_out=None, scores=None):
+        """Fused forward + loss + backward; accumulates into dE / dR; returns the summed loss as a
+        device double[1] tensor (no host sync)."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E, R, scorer)
+        B, n = batch.B, c.n
+        ws = self.workspace(B, n, t.d)
+        pos = N.Positives()
+        prow, pcol = _i32(batch.pos_row, self.device), _i32(batch.pos_col, self.device)
+        pos.row, pos.col, pos.nnz = _ptr(prow), _ptr(pcol), batch.nnz
+        if normalizer is None:
+            normalizer = float(B) * float(n)
+        if loss_out is None:
+            loss_out = torch.empty(1, dtype=torch.float64, device=self.device)
+        N.check(self.lib.okge_train_forward_backward(
+            ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), ctypes.byref(pos),
+            N.LOSSES[loss] if isinstance(loss, str) else int(loss), float(label_smoothing), float(normalizer),
+            loss_out.data_ptr(), dE.data_ptr(), dR.data_ptr(),
+            None if scores is None else scores.data_ptr(), 0 if scores is None else scores.stride(0),
+            ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_forward_backward")
+        del keep, prow, pcol
+        return loss_out
+
+    def adagrad(self, p, g, state_sum, lr, weight_decay=1e-10, eps=1e-8, zero_grad=True):
+        N.check(self.lib.okge_adagrad_step(p.data_ptr(), g.data_ptr(), state_sum.data_ptr(), p.numel(), float(lr),
+                                           float(weight_decay), float(eps), 1 if zero_grad else 0, self._stream()),
+                "okge_adagrad_step")
+
+    def filtered_ranks(self, scores, filt_ptr, filt_col, row_ptr, grp_ptr, ids):
+        """int64 ranks per answer group; all index arrays on the device (int64 ptr arrays, int32 ids)."""
+        n_groups = int(grp_ptr.numel()) - 1
+        ranks = torch.empty(n_groups, dtype=torch.int64, device=self.device)
+        B, n = scores.shape
+        N.check(self.lib.okge_filtered_ranks(scores.data_ptr(), scores.stride(0), B, n, filt_ptr.data_ptr(),
+                                             _ptr(filt_col), row_ptr.data_ptr(), grp_ptr.data_ptr(), ids.data_ptr(),
+                                             ranks.data_ptr(), self._stream()), "okge_filtered_ranks")
+        return ranks
+
+    # -- measurement --------------------------------------------------------------------------------
+    def timing(self, on):
+        self.lib.okge_timing_enable(1 if on else 0)
+        self.lib.okge_timing_reset()
+
+    def timing_collect(self):
+        return N.timing_collect()
+
+
+def positives_from_dense(labels: torch.Tensor):
+    """(B, N) {0,1} label matrix (what the reference's collate builds, dataset.py:885-932) -> coordinates
+    sorted by column.  Container plumbing for the API-compatible entry points; the fused path consumes
+    coordinates directly."""
+    idx = labels.t().nonzero()               # sorted by (col, row)
+    return idx[:, 1].to(torch.int32).contiguous(), idx[:, 0].to(torch.int32).contiguous()

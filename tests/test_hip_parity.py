@@ -1,0 +1,333 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors generated from the
+reference and against the CPU oracle on seeded inputs.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (fp32): scores |diff| <= 1e-4 (BASELINE.json north_star); we assert tighter where the
+arithmetic allows.  Ranks: bit-exact (int64)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_names
+from oracle import kge_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+SCORE_ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hp(okge_lib):
+    from open_knowledge_graph_embeddings_amd.hotpath import HotPath
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return HotPath("cuda:0")
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to("cuda:0")
+
+
+def make_batch(z_or_dict, cand=None, n_ent=None, masks=None, p=0.0, labels=None):
+    from open_knowledge_graph_embeddings_amd.hotpath import DropoutSpec, PrefixBatch, positives_from_dense
+    z = z_or_dict
+    has = (lambda k: k in z.files) if hasattr(z, "files") else (lambda k: k in z)
+    b = PrefixBatch()
+    if has("po_rel"):
+        b.po_rel, b.po_obj = dev(z["po_rel"].reshape(-1)), dev(z["po_obj"].reshape(-1))
+    if has("sp_subj"):
+        b.sp_subj, b.sp_rel = dev(z["sp_subj"].reshape(-1)), dev(z["sp_rel"].reshape(-1))
+    cand = np.asarray(cand).reshape(-1)
+    if n_ent is not None and len(cand) == n_ent - 2 and np.array_equal(cand, np.arange(2, n_ent)):
+        b.cand_first, b.n_cand = 2, len(cand)
+    else:
+        b.cand_ids, b.n_cand = dev(cand.astype(np.int32)), len(cand)
+    if masks is not None and p > 0:
+        b.drop_cand = DropoutSpec(p=p, keep=dev(masks["mask_cand"].astype(np.uint8)))
+        if has("po_rel"):
+            b.drop_po_ent = DropoutSpec(p=p, keep=dev(masks["mask_po_ent"].astype(np.uint8)))
+        if has("sp_subj"):
+            b.drop_sp_ent = DropoutSpec(p=p, keep=dev(masks["mask_sp_ent"].astype(np.uint8)))
+    if labels is not None:
+        b.pos_row, b.pos_col = positives_from_dense(dev(labels))
+    return b
+
+
+# ---------------------------------------------------------------------------------------------- G1
+@pytest.mark.parametrize("name", golden_names("g1_scores_"))
+def test_g1_scores(hp, name):
+    z = golden(name)
+    scorer = "complex" if "complex" in name else "distmult"
+    E, R = dev(z["E"]), dev(z["R"])
+    n_ent = z["E"].shape[0]
+    for cand, sp_key, po_key in ((np.arange(2, n_ent), "sp_all", "po_all"), (z["cand"], "sp_cand", "po_cand")):
+        both = {"po_rel": z["rel_po"], "po_obj": z["obj"], "sp_subj": z["subj"], "sp_rel": z["rel_sp"]}
+        out = hp.score(E, R, scorer, make_batch(both, cand, n_ent)).cpu().numpy()
+        n_po = len(z["obj"])
+        np.testing.assert_allclose(out[:n_po], z[po_key], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(out[n_po:], z[sp_key], rtol=0, atol=2e-6)
+        # one direction only (the other is None in the reference, trainer.py:73)
+        sp_only = {"sp_subj": z["subj"], "sp_rel": z["rel_sp"]}
+        out = hp.score(E, R, scorer, make_batch(sp_only, cand, n_ent)).cpu().numpy()
+        np.testing.assert_allclose(out, z[sp_key], rtol=0, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- G2
+@pytest.mark.parametrize("name", golden_names("g2_loss_"))
+def test_g2_loss_and_grads(hp, name):
+    z = golden(name)
+    scorer, loss_kind = str(z["model"]), str(z["loss_kind"])
+    p = float(z["input_dropout"])
+    E, R = dev(z["E"]), dev(z["R"])
+    batch = make_batch(z, z["cand"], z["E"].shape[0], masks=z if p > 0 else None, p=p, labels=z["labels"])
+    dE, dR = torch.zeros_like(E), torch.zeros_like(R)
+    B, Nc = z["labels"].shape
+    scores = torch.empty((B, (Nc + 3) // 4 * 4), device="cuda:0")[:, :Nc]
+    loss = hp.forward_backward(E, R, scorer, batch, dE, dR, loss=loss_kind, label_smoothing=float(z["smoothing"]),
+                               normalizer=float(z["normalizer"]), scores=scores)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(scores.cpu().numpy(), z["outputs"], rtol=0, atol=5e-6)
+    assert abs(loss.item() - float(z["loss"])) <= 2e-5 * max(1.0, abs(float(z["loss"])))
+    for mine, ref in ((dE, z["dE"]), (dR, z["dR"])):
+        scale = max(np.abs(ref).max(), 1e-12)
+        np.testing.assert_allclose(mine.cpu().numpy(), ref, rtol=0, atol=2e-5 * scale + 1e-9)
+    assert not dE[:2].any().item()          # PAD/UNK rows never receive gradient
+
+
+def test_gradients_accumulate(hp):
+    """dE/dR are accumulated into (autograd .grad semantics): two calls == twice the gradient."""
+    z = golden("g2_loss_complex_bce_all")
+    E, R = dev(z["E"]), dev(z["R"])
+    batch = make_batch(z, z["cand"], z["E"].shape[0], labels=z["labels"])
+    dE, dR = torch.zeros_like(E), torch.zeros_like(R)
+    for _ in range(2):
+        hp.forward_backward(E, R, "complex", batch, dE, dR, normalizer=float(z["normalizer"]))
+    np.testing.assert_allclose(dE.cpu().numpy(), 2 * z["dE"], rtol=0, atol=4e-5 * np.abs(z["dE"]).max())
+    np.testing.assert_allclose(dR.cpu().numpy(), 2 * z["dR"], rtol=0, atol=4e-5 * np.abs(z["dR"]).max())
+
+
+# ---------------------------------------------------------------------------------------------- G3
+@pytest.mark.parametrize("name", golden_names("g3_adagrad_"))
+def test_g3_adagrad_steps(hp, name):
+    """Each step restarted from the reference's state (see tests/test_oracle_golden.py for why)."""
+    from test_oracle_golden import adagrad_tol
+    z = golden(name)
+    scorer = "complex" if "complex" in name else "distmult"
+    lr, wd, eps = float(z["opt_lr"]), float(z["opt_weight_decay"]), float(z["opt_eps"])
+    for i in range(int(z["nsteps"])):
+        if i == 0:
+            E, R = dev(z["E0"]), dev(z["R0"])
+            sE, sR = torch.zeros_like(E), torch.zeros_like(R)
+        else:
+            E, R = dev(z[f"s{i-1}_E"]), dev(z[f"s{i-1}_R"])
+            sE, sR = dev(z[f"s{i-1}_sumE"]), dev(z[f"s{i-1}_sumR"])
+        pE, pR = sE.cpu().numpy().copy(), sR.cpu().numpy().copy()
+        step = {"po_rel": z[f"s{i}_po_rel"], "po_obj": z[f"s{i}_po_obj"], "sp_subj": z[f"s{i}_sp_subj"],
+                "sp_rel": z[f"s{i}_sp_rel"]}
+        batch = make_batch(step, z["cand"], z["E0"].shape[0], labels=z[f"s{i}_labels"])
+        dE, dR = torch.zeros_like(E), torch.zeros_like(R)
+        loss = hp.forward_backward(E, R, scorer, batch, dE, dR)
+        hp.adagrad(E, dE, sE, lr, wd, eps, zero_grad=True)
+        hp.adagrad(R, dR, sR, lr, wd, eps, zero_grad=True)
+        torch.cuda.synchronize()
+        assert abs(loss.item() - float(z[f"s{i}_loss"])) <= 2e-5 * abs(float(z[f"s{i}_loss"]))
+        assert not dE.any().item() and not dR.any().item()      # zero_grad fused into the sweep
+        for mine, ref, s_mine, s_ref, s_prev in ((E, z[f"s{i}_E"], sE, z[f"s{i}_sumE"], pE),
+                                                 (R, z[f"s{i}_R"], sR, z[f"s{i}_sumR"], pR)):
+            tol = adagrad_tol(s_ref, s_prev, lr, eps)
+            diff = np.abs(mine.cpu().numpy() - ref)
+            assert np.all(diff <= tol), float((diff / tol).max())
+            assert np.mean(diff <= 2e-6) > 0.97
+            np.testing.assert_allclose(np.sqrt(s_mine.cpu().numpy()), np.sqrt(s_ref), rtol=1e-4,
+                                       atol=1e-6 * np.sqrt(s_ref.max()))
+
+
+def test_adagrad_arithmetic_isolated(hp):
+    rng = np.random.default_rng(3)
+    for shape in ((50, 24), (7, 37), (1, 3)):                   # incl. sizes that are not multiples of 4
+        p0 = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        p, s = p0.copy(), np.zeros_like(p0)
+        pt, st = dev(p0), torch.zeros(shape, device="cuda:0")
+        for _ in range(4):
+            g = (rng.standard_normal(shape) * 10.0 ** rng.integers(-9, -2, size=shape)).astype(np.float32)
+            g[:1] = 0.0
+            gt = dev(g)
+            hp.adagrad(pt, gt, st, 0.3, 1e-10, 1e-8, zero_grad=False)
+            ko.adagrad_step(p, g, s, 0.3, 1e-10, 1e-8)
+            np.testing.assert_allclose(pt.cpu().numpy(), p, rtol=3e-7, atol=2e-7)
+            np.testing.assert_allclose(st.cpu().numpy(), s, rtol=3e-7, atol=0)
+            np.testing.assert_array_equal(gt.cpu().numpy(), g)  # zero_grad=False leaves the gradient
+
+
+# ---------------------------------------------------------------------------------------------- G5
+def ranks_args(z):
+    filt = z["filt"].astype(bool)
+    fptr = np.concatenate([[0], np.cumsum(filt.sum(1))]).astype(np.int64)
+    fcol = np.concatenate([np.nonzero(r)[0] for r in filt]).astype(np.int32)
+    return (dev(z["pred"]), dev(fptr), dev(fcol) if len(fcol) else torch.empty(0, dtype=torch.int32, device="cuda:0"),
+            dev(z["row_ptr"]), dev(z["grp_ptr"]), dev(z["ids"]))
+
+
+@pytest.mark.parametrize("name", golden_names("g5_ranks_"))
+def test_g5_ranks_bit_exact(hp, name):
+    z = golden(name)
+    ranks = hp.filtered_ranks(*ranks_args(z)).cpu().numpy()
+    assert ranks.dtype == np.int64
+    np.testing.assert_array_equal(ranks, z["ranks"])
+    m, n = ko.metrics_from_ranks(ranks, z["row_ptr"])
+    for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
+        assert abs(m[k] - float(z["m_" + k])) <= 1e-6 * max(1.0, abs(float(z["m_" + k])))
+
+
+def test_ranks_many_groups_and_ties(hp):
+    """More groups per row than the kernel's chunk of 8, heavy ties, empty filter rows."""
+    rng = np.random.default_rng(11)
+    B, Nc = 5, 3000
+    pred = (np.round(rng.standard_normal((B, Nc)) * 3) / 3).astype(np.float32)
+    filt = np.zeros((B, Nc), bool)
+    row_ptr, grp_ptr, ids = [0], [0], []
+    for b in range(B):
+        for _ in range(int(rng.integers(9, 30))):
+            g = rng.choice(Nc, size=int(rng.integers(1, 4)), replace=False)
+            ids.extend(g.tolist())
+            grp_ptr.append(len(ids))
+            if b != 2:
+                filt[b, g] = True
+        row_ptr.append(len(grp_ptr) - 1)
+    z = {"pred": pred, "filt": filt.astype(np.uint8), "row_ptr": np.asarray(row_ptr, np.int64),
+         "grp_ptr": np.asarray(grp_ptr, np.int64), "ids": np.asarray(ids, np.int32)}
+    ref = ko.filtered_ranks(pred, filt, z["row_ptr"], z["grp_ptr"], z["ids"])
+    got = hp.filtered_ranks(*ranks_args(z)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------- seeded random cases vs oracle
+def random_problem(seed, n_ent, n_rel, d, n_po, n_sp, n_cand=None, max_pos=5):
+    rng = np.random.default_rng(seed)
+    E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal((n_rel, d)) * 0.3).astype(np.float32)
+    z = {}
+    if n_po:
+        z["po_rel"], z["po_obj"] = rng.integers(2, n_rel, n_po).astype(np.int32), rng.integers(2, n_ent, n_po).astype(np.int32)
+    if n_sp:
+        z["sp_subj"], z["sp_rel"] = rng.integers(2, n_ent, n_sp).astype(np.int32), rng.integers(2, n_rel, n_sp).astype(np.int32)
+    cand = np.arange(2, n_ent) if n_cand is None else rng.permutation(np.arange(2, n_ent))[:n_cand]
+    Nc = len(cand)
+    y = np.zeros((n_po + n_sp, Nc), np.float32)
+    for b in range(n_po + n_sp):
+        y[b, rng.choice(Nc, size=int(rng.integers(1, max_pos + 1)), replace=False)] = 1
+    return E, R, z, cand.astype(np.int32), y
+
+
+def oracle_step(scorer, E, R, z, cand, y, loss_kind="bce", smoothing=0.0, **kw):
+    po = (z["po_rel"], z["po_obj"]) if "po_rel" in z else None
+    sp = (z["sp_subj"], z["sp_rel"]) if "sp_subj" in z else None
+    return ko.step_forward_backward(ko.KIND_NAMES[scorer], E, R, po, sp, cand, y, ko.LOSS_NAMES[loss_kind], smoothing, **kw)
+
+
+CASES = [
+    # scorer, n_ent, n_rel, d, n_po, n_sp, n_cand, loss, smoothing   (ragged sizes on purpose)
+    ("complex", 1000, 30, 200, 70, 61, None, "bce", 0.0),
+    ("complex", 777, 19, 64, 1, 130, None, "bce", 0.1),
+    ("complex", 400, 9, 256, 33, 0, 257, "kl", 0.0),
+    ("distmult", 900, 25, 100, 64, 64, 512, "bce", 0.0),
+    ("distmult", 333, 7, 36, 5, 3, None, "kl", 0.0),
+    ("complex", 5000, 50, 128, 100, 156, None, "bce", 0.0),
+    ("distmult", 200, 5, 17, 3, 2, None, "bce", 0.0),          # odd slot size: scalar (non-float4) paths
+    ("complex", 150, 5, 6, 2, 2, 1, "bce", 0.0),               # a single candidate
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}-d{c[3]}-b{c[4]}+{c[5]}-{c[7]}" for c in CASES])
+def test_random_vs_oracle(hp, case):
+    scorer, n_ent, n_rel, d, n_po, n_sp, n_cand, loss_kind, smoothing = case
+    E, R, z, cand, y = random_problem(100 + CASES.index(case), n_ent, n_rel, d, n_po, n_sp, n_cand)
+    ref = oracle_step(scorer, E, R, z, cand, y, loss_kind, smoothing)
+    Et, Rt = dev(E), dev(R)
+    batch = make_batch(z, cand, n_ent, labels=y)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = hp.forward_backward(Et, Rt, scorer, batch, dE, dR, loss=loss_kind, label_smoothing=smoothing)
+    out = hp.score(Et, Rt, scorer, batch).cpu().numpy()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out, ref["outputs"], rtol=0, atol=SCORE_ATOL)
+    assert np.abs(out - ref["outputs"]).max() <= 3e-6 * max(1.0, np.abs(ref["outputs"]).max())
+    assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+    for mine, r in ((dE, ref["dE"]), (dR, ref["dR"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=3e-5 * np.abs(r).max() + 1e-12)
+
+
+def test_b_split_path(hp, monkeypatch):
+    """Few candidate tiles -> the batch is split across blockIdx.y and dC goes through atomics."""
+    E, R, z, cand, y = random_problem(5, 300, 11, 64, 200, 184, 100)
+    ref = oracle_step("complex", E, R, z, cand, y)
+    Et, Rt = dev(E), dev(R)
+    batch = make_batch(z, cand, 300, labels=y)
+    for split in ("1", "3", "6"):
+        monkeypatch.setenv("OKGE_B_SPLIT", split)
+        dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+        loss = hp.forward_backward(Et, Rt, "complex", batch, dE, dR)
+        torch.cuda.synchronize()
+        assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+        np.testing.assert_allclose(dE.cpu().numpy(), ref["dE"], rtol=0, atol=3e-5 * np.abs(ref["dE"]).max())
+        np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
+
+
+# ------------------------------------------------------------------------------- counter-based dropout
+@pytest.mark.parametrize("scorer", ["complex", "distmult"])
+def test_philox_dropout_matches_oracle_masks(hp, scorer):
+    """The kernels' Philox masks are integer work: identical to the oracle's, so the whole step matches."""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    n_ent, n_rel, d, n_po, n_sp = 500, 12, 200, 40, 37
+    E, R, z, cand, y = random_problem(21, n_ent, n_rel, d, n_po, n_sp)
+    p, p_rel, seed, step = 0.4, 0.25, 0xDEADBEEFCAFE, 7
+    Nc = len(cand)
+    keep = {
+        "keep_cand": ko.dropout_keep_mask(seed, H.STREAM_CAND, step, Nc, d, p),
+        "keep_po_ent": ko.dropout_keep_mask(seed, H.STREAM_PO_ENT, step, n_po, d, p),
+        "keep_sp_ent": ko.dropout_keep_mask(seed, H.STREAM_SP_ENT, step, n_sp, d, p),
+        "keep_po_rel": ko.dropout_keep_mask(seed, H.STREAM_PO_REL, step, n_po, d, p_rel),
+        "keep_sp_rel": ko.dropout_keep_mask(seed, H.STREAM_SP_REL, step, n_sp, d, p_rel),
+    }
+    ref = oracle_step(scorer, E, R, z, cand, y, p_ent=p, p_rel=p_rel, **keep)
+    batch = make_batch(z, cand, n_ent, labels=y)
+    batch.drop_cand = H.DropoutSpec(p, seed, H.STREAM_CAND, step)
+    batch.drop_po_ent = H.DropoutSpec(p, seed, H.STREAM_PO_ENT, step)
+    batch.drop_sp_ent = H.DropoutSpec(p, seed, H.STREAM_SP_ENT, step)
+    batch.drop_po_rel = H.DropoutSpec(p_rel, seed, H.STREAM_PO_REL, step)
+    batch.drop_sp_rel = H.DropoutSpec(p_rel, seed, H.STREAM_SP_REL, step)
+    Et, Rt = dev(E), dev(R)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = hp.forward_backward(Et, Rt, scorer, batch, dE, dR)
+    out = hp.score(Et, Rt, scorer, batch).cpu().numpy()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out, ref["outputs"], rtol=0, atol=1e-5)
+    assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+    np.testing.assert_allclose(dE.cpu().numpy(), ref["dE"], rtol=0, atol=3e-5 * np.abs(ref["dE"]).max())
+    np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
+
+
+# ------------------------------------------------------------------------------- BASELINE.json full size
+def test_full_size_fb15k237_shape(hp):
+    """configs[1]: |E|=14543, |R|=239, d=200, B=512 (256 po + 256 sp), N=14541, 1-vs-all, BCE."""
+    n_ent, n_rel, d = 14543, 239, 200
+    E, R, z, cand, y = random_problem(1234, n_ent, n_rel, d, 256, 256, None, max_pos=8)
+    E *= 1 / 3.0
+    ref = oracle_step("complex", E, R, z, cand, y)
+    Et, Rt = dev(E), dev(R)
+    batch = make_batch(z, cand, n_ent, labels=y)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = hp.forward_backward(Et, Rt, "complex", batch, dE, dR)
+    out = hp.score(Et, Rt, "complex", batch).cpu().numpy()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out, ref["outputs"], rtol=0, atol=SCORE_ATOL)
+    assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+    np.testing.assert_allclose(dE.cpu().numpy(), ref["dE"], rtol=0, atol=3e-5 * np.abs(ref["dE"]).max())
+    np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
+    # size-independent properties: (1) the gradient of the summed loss w.r.t. scores sums to
+    # sum(sigmoid(x)) - nnz, which the entity gradient inherits through linearity in Q;
+    # (2) scoring a candidate subset equals the matching columns of the full score matrix
+    sub = np.sort(np.random.default_rng(0).choice(len(cand), 1000, replace=False))
+    b2 = make_batch(z, cand[sub], n_ent)
+    out_sub = hp.score(Et, Rt, "complex", b2).cpu().numpy()
+    np.testing.assert_array_equal(out_sub, out[:, sub])
