@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Benchmark of the open-KGE hot path on MI355X: training triples/sec, 1-vs-all ComplEx d=200
+(BASELINE.json metric), synthetic FB15k-237-shaped data (workload "S-FB").
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: gather+dropout, score all candidates, BCE loss,
+backward, dense Adagrad on both tables (what Trainer.compute_one_batch does, openkge/trainer.py:181-257).
+All inputs (tables, batches) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+N_BATCHES = 8                   # distinct pre-generated batches cycled through
+
+
+def to_dev_batch(hb, w, dev):
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    return PrefixBatch(po_rel=t(hb["po_rel"]), po_obj=t(hb["po_obj"]), sp_subj=t(hb["sp_subj"]), sp_rel=t(hb["sp_rel"]),
+                       pos_row=t(hb["pos_row"]), pos_col=t(hb["pos_col"]), cand_first=2, n_cand=w.N)
+
+
+def cpu_baseline(w, host_batches, budget_s=20.0):
+    """The reference's ATen op sequence on the host cores (oracle/torch_twin.py, kind 'port'), bounded."""
+    from oracle import torch_twin
+    from open_knowledge_graph_embeddings_amd import synthetic
+    torch.set_num_threads(os.cpu_count())          # as the reference does (trainer.py:136)
+    torch.manual_seed(1234)
+    m = torch_twin.TwinModel(w.scorer, w.n_ent, w.n_rel, w.d, input_dropout=w.input_dropout, init_std=w.init_std)
+    m.train()
+    opt = torch_twin.make_adagrad(m, lr=w.lr)
+    cand = torch.arange(w.n_ent)[2:].int().unsqueeze(1)
+    prepared = []
+    for hb in host_batches[:4]:
+        y = torch.from_numpy(synthetic.dense_labels(hb, w.B, w.N))
+        po = (torch.from_numpy(hb["po_rel"]).unsqueeze(1), torch.from_numpy(hb["po_obj"]).unsqueeze(1))
+        sp = (torch.from_numpy(hb["sp_subj"]).unsqueeze(1), torch.from_numpy(hb["sp_rel"]).unsqueeze(1))
+        prepared.append((po, sp, y, hb["n_pos"]))
+    for i in range(3):
+        po, sp, y, _ = prepared[i % len(prepared)]
+        torch_twin.train_step(m, opt, po, sp, cand, y)
+    t0 = time.perf_counter()
+    steps, triples = 0, 0
+    while True:
+        po, sp, y, n_pos = prepared[steps % len(prepared)]
+        torch_twin.train_step(m, opt, po, sp, cand, y)
+        steps += 1
+        triples += n_pos
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 200:
+            break
+    return {"value": triples / el, "unit": "triples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} steps of {w.name} (B={w.B}, N={w.N}, d={w.d}) in {el:.1f}s, torch-CPU twin of the "
+                      f"reference op sequence, dense labels prebuilt, no dataloader",
+            "ms_per_step": 1e3 * el / steps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="S-FB")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from open_knowledge_graph_embeddings_amd import synthetic
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = synthetic.WORKLOADS[args.workload]
+    E, R = synthetic.make_tables(w, seed=1234)
+    # N > 1: independent data shards -- every rank trains its own replica on its own batches (see DESIGN.md
+    # "Multi-GPU"); the entity-sharded exchange path is exercised by tests/test_sharded.py.
+    host_batches = [synthetic.make_batch(w, seed=1234 + 1000 * rank + i) for i in range(N_BATCHES)]
+    Et, Rt = torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev)
+    step = FusedTrainStep(Et, Rt, w.scorer, loss=w.loss, lr=w.lr, input_dropout=w.input_dropout, seed=1234)
+    batches = [to_dev_batch(hb, w, dev) for hb in host_batches]
+    n_pos = [hb["n_pos"] for hb in host_batches]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step.step(batches[i % N_BATCHES])
+    barrier()
+    t0 = time.perf_counter()
+    triples = 0
+    for i in range(args.steps):
+        step.step(batches[i % N_BATCHES])
+        triples += n_pos[i % N_BATCHES]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    loss_last = float(step.loss_out.item())
+    if dist is not None:
+        tt = torch.tensor([elapsed, float(triples)], dtype=torch.float64, device=dev)
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed, triples = float(tmax[0].item()), float(tt[1].item())
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, separate pass ------------------
+    roof = None
+    if rank == 0:
+        eng = step.engine
+        eng.timing(True)
+        ksteps = min(args.steps, 50)
+        for i in range(ksteps):
+            step.step(batches[i % N_BATCHES])
+        torch.cuda.synchronize()
+        per_kernel = eng.timing_collect()
+        eng.timing(False)
+        tot_ms, cnt = per_kernel["fused_tile_train"]
+        avg_s = tot_ms / cnt * 1e-3
+        flops = 4.0 * w.B * w.N * w.d                 # X = Q.C^T (2BNd) + dC = G^T.Q (2BNd) per launch
+        achieved = flops / avg_s / 1e12
+        roof = {"bound": "mfma", "kernel": "fused_tile_kernel<train>", "achieved": achieved,
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None, "avg_launch_us": avg_s * 1e6,
+                "kernels_us": {k: v[0] / v[1] * 1e3 for k, v in per_kernel.items()},
+                "step_flops_6BNd": 6.0 * w.B * w.N * w.d, "step_bytes_20Nd": 20.0 * w.N * w.d}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(w, host_batches)
+    line = {
+        "metric": "training triples/sec (1-vs-all ComplEx d=200)", "value": triples / elapsed, "unit": "triples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{w.name}: FB15k-237-shaped |E|={w.n_ent} |R|={w.n_rel} d={w.d} ComplEx 1-vs-all "
+                               f"N={w.N}, B={w.B} ({w.n_po} po + {w.n_sp} sp), BCE, input_dropout {w.input_dropout}, "
+                               f"dense Adagrad lr {w.lr}",
+                   "global_batch": w.B * world, "parallelism": f"replicas x{world}" if world > 1 else "single"},
+        "prefixes_per_s": w.B * world * args.steps / elapsed, "last_loss_sum": loss_last,
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -216,7 +216,7 @@ def random_problem(seed, n_ent, n_rel, d, n_po, n_sp, n_cand=None, max_pos=5):
     Nc = len(cand)
     y = np.zeros((n_po + n_sp, Nc), np.float32)
     for b in range(n_po + n_sp):
-        y[b, rng.choice(Nc, size=int(rng.integers(1, max_pos + 1)), replace=False)] = 1
+        y[b, rng.choice(Nc, size=int(rng.integers(1, min(max_pos, Nc) + 1)), replace=False)] = 1
     return E, R, z, cand.astype(np.int32), y
 
 
