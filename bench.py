@@ -34,11 +34,40 @@ def to_dev_batch(hb, w, dev):
                        pos_row=t(hb["pos_row"]), pos_col=t(hb["pos_col"]), cand_first=2, n_cand=w.N)
 
 
+def host_cores():
+    """Cores this process may actually use: affinity, then the cgroup CPU quota; the GPU boxes expose all 256
+    host threads to os.cpu_count() but give a one-GPU job a 16-core share."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    if "OKGE_CPU_THREADS" in os.environ:
+        n = int(os.environ["OKGE_CPU_THREADS"])
+    elif n > 32:
+        n = 16          # documented CPU share of a one-GPU box
+    return n
+
+
 def cpu_baseline(w, host_batches, budget_s=20.0):
     """The reference's ATen op sequence on the host cores (oracle/torch_twin.py, kind 'port'), bounded."""
     from oracle import torch_twin
     from open_knowledge_graph_embeddings_amd import synthetic
-    torch.set_num_threads(os.cpu_count())          # as the reference does (trainer.py:136)
+    # the reference uses every core it sees (trainer.py:136); here: every core this job may use
+    torch.set_num_threads(host_cores())
     torch.manual_seed(1234)
     m = torch_twin.TwinModel(w.scorer, w.n_ent, w.n_rel, w.d, input_dropout=w.input_dropout, init_std=w.init_std)
     m.train()

@@ -43,8 +43,9 @@ enum okge_loss   { OKGE_LOSS_BCE = 0, OKGE_LOSS_KL = 1 };   /* trainer.py:93-106
 /* Dropout applied to gathered embedding rows (model.py:461-462, F.dropout in training mode).
  * p == 0 disables it.  If `keep` is non-NULL it is an explicit keep-mask, uint8 [rows][d]
  * (1 = keep) -- used for parity runs against masks captured from the reference; otherwise the mask
- * is Philox4x32-10(key = seed, counter = (row position, column/4, stream, step)), word column&3,
- * keep <=> word >= floor(p * 2^32).  Kept values are multiplied by 1/(1-p). */
+ * is Philox4x32-10(key = seed, counter = (row position, column/8, stream, step)) read as eight 16-bit
+ * numbers (element column&7: word (column&7)/2, low half if even, high half if odd),
+ * keep <=> number >= floor(p * 65536).  Kept values are multiplied by 1/(1-p). */
 typedef struct okge_dropout {
     float          p;
     uint32_t       stream;
@@ -118,10 +119,13 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
  *               (like autograd's .grad); they must be zero (or hold earlier accumulation) on entry
  *   scores    : optional [B][ld_scores] output of all_outputs (NULL to skip -- training never needs it)
  *   normalizer: the reference divides the loss by B*N before backward (dataset.py:935)
+ *   flags     : OKGE_TRAIN_GRADS_ZERO -- the caller guarantees dE and dR are all-zero on entry (fresh
+ *               zero_grad, trainer.py:229-232); candidate rows are then stored instead of read-modify-written
  * No (B,N) label or score tensor is read; positives come as coordinates. */
+#define OKGE_TRAIN_GRADS_ZERO 1
 int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch,
                                 const okge_candidates *cand, const okge_positives *pos,
-                                int32_t loss_kind, float label_smoothing, double normalizer,
+                                int32_t loss_kind, float label_smoothing, double normalizer, int32_t flags,
                                 double *loss_out, float *dE, float *dR,
                                 float *scores, int64_t ld_scores,
                                 void *workspace, size_t workspace_bytes, void *stream);
@@ -136,6 +140,9 @@ size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d);
  * gradient buffer is cleared in the same sweep (replaces optimizer.zero_grad(), trainer.py:229-244). */
 int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr, float weight_decay,
                       float eps, int32_t zero_grad, void *stream);
+/* The same update on two parameter tensors (entity and relation table) in ONE launch. */
+int okge_adagrad_step2(float *p0, float *g0, float *sum0, int64_t n0, float *p1, float *g1, float *sum1,
+                       int64_t n1, float lr, float weight_decay, float eps, int32_t zero_grad, void *stream);
 
 /* ---- filtered ranks ---------------------------------------------------------------------------------
  * Replaces OneToNMentionRelationDataset.compute_metrics' rank rule (dataset.py:423-446):

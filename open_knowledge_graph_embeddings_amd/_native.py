@@ -19,12 +19,13 @@ HEADERS = ["okge_device.h", "okge_kernels.h", os.path.join("..", "..", "include"
 
 OKGE_COMPLEX, OKGE_DISTMULT = 0, 1
 OKGE_LOSS_BCE, OKGE_LOSS_KL = 0, 1
+OKGE_TRAIN_GRADS_ZERO = 1
 SCORERS = {"complex": OKGE_COMPLEX, "distmult": OKGE_DISTMULT}
 LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 
 # every symbol include/okge.h declares
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
-           "okge_train_workspace_bytes", "okge_adagrad_step", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_train_workspace_bytes", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -95,10 +96,13 @@ def lib():
                                       c_void_p, c_size_t, c_void_p]
     L.okge_train_forward_backward.restype = c_int32
     L.okge_train_forward_backward.argtypes = [POINTER(Tables), POINTER(PrefixBatch), POINTER(Candidates),
-                                              POINTER(Positives), c_int32, c_float, c_double, c_void_p, c_void_p,
-                                              c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]
+                                              POINTER(Positives), c_int32, c_float, c_double, c_int32, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]
     L.okge_adagrad_step.restype = c_int32
     L.okge_adagrad_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int32, c_void_p]
+    L.okge_adagrad_step2.restype = c_int32
+    L.okge_adagrad_step2.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_float, c_float, c_float, c_int32, c_void_p]
     L.okge_filtered_ranks.restype = c_int32
     L.okge_filtered_ranks.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p]

@@ -87,8 +87,8 @@ DropDev to_dev(const okge_dropout &d)
         r.enabled = 1;
         r.keep = d.keep;
         r.scale = 1.0f / (1.0f - d.p);
-        const double t = (double)d.p * 4294967296.0;
-        r.thr = t <= 0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+        const double t = (double)d.p * 65536.0;
+        r.thr = t <= 0 ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
         r.k0 = (uint32_t)d.seed;
         r.k1 = (uint32_t)(d.seed >> 32);
         r.stream = d.stream;
@@ -110,8 +110,8 @@ PrefixDev to_dev(const okge_prefix_batch &b)
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Geometry {
-    int    B, N, d, Bpad, D16, KB, LDK, ldq, ldgt, tiles, b_split, b_per_block, nsplit;
-    size_t off_Q, off_GT, off_slab, off_loss, off_stats, off_lse, off_ysum, total;
+    int    B, N, d, Bpad, D16, KB, LDK, ldq, ldg, tiles, b_split, b_per_block, nsplit;
+    size_t off_Q, off_tptr, off_GT, off_Cm, off_slab, off_loss, off_stats, off_lse, off_ysum, total;
 };
 
 int env_int(const char *name, int dflt)
@@ -125,12 +125,15 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     if (B <= 0 || N <= 0 || d <= 0) return false;
     g.B = B; g.N = N; g.d = d;
     g.Bpad = (B + BC - 1) / BC * BC;
-    g.D16 = (d + 15) / 16 * 16;
-    g.KB = g.D16 / 16;
+    // slot size padded to a width the tile kernels are instantiated for (zero columns are free of error,
+    // not of time: d in (128, 208] runs as 208, etc.)
+    const int kb = (d + 15) / 16;
+    g.KB = kb <= 4 ? 4 : kb <= 8 ? 8 : kb <= 13 ? 13 : 16;
+    g.D16 = 16 * g.KB;
     g.LDK = lds_ld(g.D16);
     g.ldq = g.D16;
-    g.ldgt = g.Bpad;
     g.tiles = (N + NT - 1) / NT;
+    g.ldg = g.tiles * NT;
     const int bblks = g.Bpad / BC;
     // fill the 256 CUs: if there are few candidate tiles, split the batch rows across blockIdx.y
     int bs = 1;
@@ -140,14 +143,16 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.b_per_block = (bblks + bs - 1) / bs * BC;
     g.b_split = (g.Bpad + g.b_per_block - 1) / g.b_per_block;
     // dQ kernel: (batch block, candidate range) workgroups, about two per CU
-    int ns = std::max(1, 512 / bblks);
+    int ns = std::max(1, 256 / bblks);
     ns = env_int("OKGE_DQ_SPLIT", ns);
     ns = std::max(1, std::min(ns, g.tiles));
     if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
     g.nsplit = ns;
     size_t off = 0;
     g.off_Q = off;     off += align_up((size_t)g.Bpad * g.ldq * sizeof(float), 256);
-    g.off_GT = off;    off += align_up((size_t)N * g.ldgt * sizeof(float), 256);
+    g.off_tptr = off;  off += align_up((size_t)(g.tiles + 1) * sizeof(int32_t), 256);
+    g.off_GT = off;    off += align_up((size_t)g.Bpad * g.ldg * sizeof(float), 256);
+    g.off_Cm = off;    off += align_up((size_t)g.tiles * NT * g.D16 * sizeof(float), 256);
     g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
     g.off_loss = off;  off += align_up((size_t)g.tiles * g.b_split * sizeof(double), 256);
     g.off_stats = off; off += align_up((size_t)g.tiles * g.Bpad * 2 * sizeof(float), 256);
@@ -183,7 +188,7 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
     a.cand_first = c->first_id;
     a.Q = reinterpret_cast<const float *>(ws + g.off_Q);
     a.drop_c = to_dev(c->drop);
-    a.d = g.d; a.KB = g.KB; a.LDK = g.LDK; a.N = g.N; a.B = g.B; a.Bpad = g.Bpad; a.ldq = g.ldq; a.ldgt = g.ldgt;
+    a.d = g.d; a.KB = g.KB; a.LDK = g.LDK; a.N = g.N; a.B = g.B; a.Bpad = g.Bpad; a.ldq = g.ldq; a.ldg = g.ldg;
     a.b_per_block = g.b_per_block;
 }
 
@@ -209,7 +214,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     if (!scores || ld_scores < cand->n) return fail(OKGE_ERR_INVALID, "bad scores buffer");
     Geometry g;
     make_geometry(batch->n_po + batch->n_sp, cand->n, t->d, g);
-    const size_t need = g.off_GT;   // only the query block
+    const size_t need = g.off_tptr;   // only the query block
     if (!workspace || workspace_bytes < need) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
@@ -217,7 +222,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     {
         ScopedTimer tm("encode_queries", st);
         hipError_t e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q),
-                                             g.ldq, g.Bpad, st);
+                                             g.ldq, g.Bpad, nullptr, 0, nullptr, g.tiles, st);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
@@ -236,8 +241,9 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
 
 int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
                                 const okge_positives *pos, int32_t loss_kind, float label_smoothing,
-                                double normalizer, double *loss_out, float *dE, float *dR, float *scores,
-                                int64_t ld_scores, void *workspace, size_t workspace_bytes, void *stream)
+                                double normalizer, int32_t flags, double *loss_out, float *dE, float *dR,
+                                float *scores, int64_t ld_scores, void *workspace, size_t workspace_bytes,
+                                void *stream)
 {
     if (int rc = check_common(t, batch, cand)) return rc;
     if (!pos || pos->nnz < 0 || (pos->nnz > 0 && (!pos->col || !pos->row)))
@@ -256,13 +262,16 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     {
         ScopedTimer tm("encode_queries", st);
         e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
-                                  g.Bpad, st);
+                                  g.Bpad, pos->col, pos->nnz, reinterpret_cast<int32_t *>(ws + g.off_tptr), g.tiles, st);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
     fill_fused_common(a, g, t, cand, ws);
     a.pos_col = pos->col; a.pos_row = pos->row; a.nnz = pos->nnz;
-    a.GT = reinterpret_cast<float *>(ws + g.off_GT);
+    a.tile_ptr = reinterpret_cast<const int32_t *>(ws + g.off_tptr);
+    a.grads_zero = (flags & OKGE_TRAIN_GRADS_ZERO) ? 1 : 0;
+    a.G = reinterpret_cast<float *>(ws + g.off_GT);
+    a.Cm = reinterpret_cast<float *>(ws + g.off_Cm);
     a.dE = dE;
     a.loss_partial = reinterpret_cast<double *>(ws + g.off_loss);
     a.loss_kind = loss_kind;
@@ -299,17 +308,19 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
         a.row_lse = reinterpret_cast<const float *>(ws + g.off_lse);
         a.row_ysum = reinterpret_cast<const float *>(ws + g.off_ysum);
     }
+#ifdef OKGE_STAMPS
+    if (const char *sp = std::getenv("OKGE_STAMPS_PTR")) a.stamps_dbg = reinterpret_cast<unsigned long long *>(std::strtoull(sp, nullptr, 0));
+#endif
     {
         ScopedTimer tm("fused_tile_train", st);
-        e = launch_fused(MODE_TRAIN, a, g.tiles, g.b_split, st);
+        e = launch_fused(loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE, a, g.tiles, g.b_split, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
     }
     DqArgs q;
     std::memset(&q, 0, sizeof(q));
-    q.E = t->E; q.cand_ids = cand->ids; q.cand_first = cand->first_id; q.GT = a.GT;
+    q.G = a.G; q.Cm = a.Cm;
     q.slab = reinterpret_cast<float *>(ws + g.off_slab);
-    q.drop_c = a.drop_c;
-    q.d = g.d; q.KB = g.KB; q.LDK = g.LDK; q.N = g.N; q.Bpad = g.Bpad; q.ldq = g.ldq; q.ldgt = g.ldgt;
+    q.d = g.d; q.KB = g.KB; q.LDK = g.LDK; q.N = g.N; q.Bpad = g.Bpad; q.ldq = g.ldq; q.ldg = g.ldg;
     q.nsplit = g.nsplit;
     {
         ScopedTimer tm("dq", st);
@@ -317,14 +328,10 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
         if (e != hipSuccess) return fail_hip(e, "dq_kernel");
     }
     {
-        ScopedTimer tm("prefix_backward", st);
-        e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, dE, dR, st);
+        ScopedTimer tm("prefix_backward", st);      // + the deterministic loss reduction (one extra workgroup)
+        e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, dE, dR,
+                                   a.loss_partial, g.tiles * g.b_split, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
-    }
-    {
-        ScopedTimer tm("loss_reduce", st);
-        e = launch_loss_reduce(a.loss_partial, g.tiles * g.b_split, loss_out, st);
-        if (e != hipSuccess) return fail_hip(e, "loss_reduce");
     }
     return OKGE_OK;
 }
@@ -338,6 +345,21 @@ int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ScopedTimer tm("adagrad", st);
     hipError_t e = launch_adagrad(p, g, state_sum, n, lr, weight_decay, eps, zero_grad, st);
+    if (e != hipSuccess) return fail_hip(e, "adagrad");
+    return OKGE_OK;
+}
+
+int okge_adagrad_step2(float *p0, float *g0, float *sum0, int64_t n0, float *p1, float *g1, float *sum1, int64_t n1,
+                       float lr, float weight_decay, float eps, int32_t zero_grad, void *stream)
+{
+    if (!p0 || !g0 || !sum0 || n0 < 0 || !p1 || !g1 || !sum1 || n1 < 0)
+        return fail(OKGE_ERR_INVALID, "bad adagrad arguments");
+    if ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(g0) | reinterpret_cast<uintptr_t>(sum0) |
+         reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(sum1)) % 16)
+        return fail(OKGE_ERR_INVALID, "adagrad buffers must be 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("adagrad", st);
+    hipError_t e = launch_adagrad2(p0, g0, sum0, n0, p1, g1, sum1, n1, lr, weight_decay, eps, zero_grad, st);
     if (e != hipSuccess) return fail_hip(e, "adagrad");
     return OKGE_OK;
 }

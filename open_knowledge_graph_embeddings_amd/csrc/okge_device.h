@@ -14,7 +14,7 @@ constexpr int WAVE = 64;
 struct DropDev {
     const uint8_t *keep;   // explicit keep mask [rows][d] or nullptr
     float          scale;  // 1/(1-p)   (1 when disabled)
-    uint32_t       thr;    // keep <=> philox word >= thr
+    uint32_t       thr;    // keep <=> 16-bit philox number >= thr (= floor(p * 65536))
     uint32_t       k0, k1; // philox key = seed
     uint32_t       stream, step;
     int32_t        enabled;
@@ -36,36 +36,46 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return make_uint4(c0, c1, c2, c3);
 }
 
-// Multipliers (0 or 1/(1-p)) for the four columns 4*q4 .. 4*q4+3 of row `row_pos` of a gathered block
-// whose rows have `d` columns.  Columns >= d return 0.
-__device__ __forceinline__ float4 drop_mult4(const DropDev &dr, uint32_t row_pos, int q4, int d)
+// Keep flags (bit e = column 8*o8 + e) of eight consecutive columns of row `row_pos` of a gathered block with
+// `d` columns.  One Philox call yields 8 uniform 16-bit numbers: word e>>1, low half for even e, high half
+// for odd e; keep <=> u16 >= thr (thr = floor(p * 65536)).  Columns >= d report "drop".
+__device__ __forceinline__ uint32_t drop_keep8(const DropDev &dr, uint32_t row_pos, int o8, int d)
 {
-    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (!dr.enabled) return m;
+    uint32_t bits = 0;
     if (dr.keep) {
-        const uint8_t *kp = dr.keep + (size_t)row_pos * d + 4 * q4;
-        const int k = 4 * q4;
-        m.x = (k + 0 < d && kp[0]) ? dr.scale : 0.f;
-        m.y = (k + 1 < d && kp[1]) ? dr.scale : 0.f;
-        m.z = (k + 2 < d && kp[2]) ? dr.scale : 0.f;
-        m.w = (k + 3 < d && kp[3]) ? dr.scale : 0.f;
-        return m;
+        const uint8_t *kp = dr.keep + (size_t)row_pos * d + 8 * o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (8 * o8 + e < d && kp[e]) bits |= 1u << e;
+        return bits;
     }
-    const uint4 u = philox4x32_10(row_pos, (uint32_t)q4, dr.stream, dr.step, dr.k0, dr.k1);
-    m.x = u.x >= dr.thr ? dr.scale : 0.f;
-    m.y = u.y >= dr.thr ? dr.scale : 0.f;
-    m.z = u.z >= dr.thr ? dr.scale : 0.f;
-    m.w = u.w >= dr.thr ? dr.scale : 0.f;
-    return m;
+    const uint4 u = philox4x32_10(row_pos, (uint32_t)o8, dr.stream, dr.step, dr.k0, dr.k1);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t u16 = (w[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+        if (u16 >= dr.thr && 8 * o8 + e < d) bits |= 1u << e;
+    }
+    return bits;
 }
 
 __device__ __forceinline__ float drop_mult1(const DropDev &dr, uint32_t row_pos, int k, int d)
 {
     if (!dr.enabled) return 1.f;
     if (dr.keep) return dr.keep[(size_t)row_pos * d + k] ? dr.scale : 0.f;
-    const uint4 u = philox4x32_10(row_pos, (uint32_t)(k >> 2), dr.stream, dr.step, dr.k0, dr.k1);
-    const uint32_t w = (k & 3) == 0 ? u.x : (k & 3) == 1 ? u.y : (k & 3) == 2 ? u.z : u.w;
-    return w >= dr.thr ? dr.scale : 0.f;
+    const uint4 u = philox4x32_10(row_pos, (uint32_t)(k >> 3), dr.stream, dr.step, dr.k0, dr.k1);
+    const int e = k & 7;
+    const uint32_t w = (e >> 1) == 0 ? u.x : (e >> 1) == 1 ? u.y : (e >> 1) == 2 ? u.z : u.w;
+    return ((w >> (16 * (e & 1))) & 0xFFFFu) >= dr.thr ? dr.scale : 0.f;
+}
+
+// v *= (keep ? scale : 0) for the 4 columns selected by bits (nibble already shifted down)
+__device__ __forceinline__ void apply_keep4(float4 &v, uint32_t nibble, float scale)
+{
+    v.x *= (nibble & 1u) ? scale : 0.f;
+    v.y *= (nibble & 2u) ? scale : 0.f;
+    v.z *= (nibble & 4u) ? scale : 0.f;
+    v.w *= (nibble & 8u) ? scale : 0.f;
 }
 
 // D(16x16) += A(16x4) * B(4x16), exact fp32.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
@@ -92,6 +102,16 @@ __device__ __forceinline__ int wave_sum(int v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+
+__device__ __forceinline__ int lower_bound_i32(const int32_t *__restrict__ a, int n, int key)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 // Padded leading dimension (floats) of an LDS tile whose rows hold D16 floats: D16 + 4 = 4 * odd, so

@@ -11,7 +11,7 @@ constexpr int BC = 64;             // batch rows per chunk
 constexpr int LDG = 68;            // leading dimension of the 64x64 G / X tile in LDS (4*odd)
 constexpr int FUSED_THREADS = 256; // 4 waves, one per SIMD
 
-enum { MODE_TRAIN = 0, MODE_SCORE = 1, MODE_STATS = 2 };
+enum { MODE_TRAIN_BCE = 0, MODE_SCORE = 1, MODE_STATS = 2, MODE_TRAIN_KL = 3 };
 enum { LOSS_BCE = 0, LOSS_KL = 1 };
 enum { SC_COMPLEX = 0, SC_DISTMULT = 1 };
 
@@ -20,25 +20,26 @@ struct FusedArgs {
     const int32_t *cand_ids;   // nullptr => cand_first + position
     const float   *Q;          // folded queries [Bpad][ldq], zero padded to ldq >= D16
     const int32_t *pos_col, *pos_row;
+    const int32_t *tile_ptr;   // [tiles + 1] offsets into pos_* per candidate tile
     const float   *row_lse, *row_ysum;   // KL
-    float         *GT;         // [N][ldgt]  G^T
+    float         *G;          // [Bpad][ldg]  dLoss/dX / normalizer, row-major, ldg = 64 * tiles
+    float         *Cm;         // [64 * tiles][16*KB]  masked (dropped-out) candidate rows, for dq_kernel
     float         *dE;
     double        *loss_partial;
     float         *X;          // score mode
     float         *stats;      // stats mode: float2 [tiles][Bpad]
+    unsigned long long *stamps_dbg;   // diagnostic build (-DOKGE_STAMPS) only
     int64_t        ldx;
     DropDev        drop_c;
-    int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldgt, nnz, b_per_block, loss_kind, x_vec_ok;
+    int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero;
     float          y_pos, y_neg, inv_norm;
 };
 
 struct DqArgs {
-    const float   *E;
-    const int32_t *cand_ids;
-    const float   *GT;
+    const float   *G;
+    const float   *Cm;         // masked candidate rows written by fused_tile_kernel
     float         *slab;       // [nsplit][Bpad][ldq]
-    DropDev        drop_c;
-    int32_t        d, KB, LDK, cand_first, N, Bpad, ldq, ldgt, nsplit;
+    int32_t        d, KB, LDK, N, Bpad, ldq, ldg, nsplit;
 };
 
 struct PrefixDev {
@@ -53,15 +54,17 @@ hipError_t launch_fused(int mode, const FusedArgs &a, int grid_x, int grid_y, hi
 hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st);
 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
-                                 int ldq, int Bpad, hipStream_t st);
+                                 int ldq, int Bpad, const int32_t *pos_col, int nnz, int32_t *tile_ptr, int tiles,
+                                 hipStream_t st);
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
                                   const float *slab, int nsplit, int Bpad, int ldq, float *dE, float *dR,
-                                  hipStream_t st);
-hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
+                                  const double *loss_partials, int n_partials, double *loss_out, hipStream_t st);
 hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, const int32_t *pos_row, int nnz,
                                float *row_lse, float *row_ysum, hipStream_t st);
 hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, float wd, float eps, int zero_grad,
                           hipStream_t st);
+hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p1, float *g1, float *s1, int64_t n1,
+                           float lr, float wd, float eps, int zero_grad, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, hipStream_t st);

@@ -5,6 +5,8 @@
 //   kl_* kernels            log-sum-exp per row from tile partials, positives per row  trainer.py:99-100
 //   adagrad_kernel          dense Adagrad sweep (+ zero_grad)                          utils/optim.py:139-160 / torch.optim.Adagrad
 //   ranks_kernel            filtered ranks, exact integer counts                       dataset.py:423-446
+#include <algorithm>
+
 #include "okge_device.h"
 #include "okge_kernels.h"
 
@@ -30,8 +32,16 @@ __device__ __forceinline__ RowSrc row_source(const PrefixDev &p, int b)
 
 __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                              int d, int scorer, const PrefixDev p,
-                                                             float *__restrict__ Q, int ldq)
+                                                             float *__restrict__ Q, int ldq, int Bpad,
+                                                             const int32_t *__restrict__ pos_col, int nnz,
+                                                             int32_t *__restrict__ tile_ptr, int tiles)
 {
+    if ((int)blockIdx.x >= Bpad) {
+        // extra workgroups: offsets of each candidate tile's positives in the column-sorted coordinate list
+        const int t = ((int)blockIdx.x - Bpad) * 128 + threadIdx.x;
+        if (t <= tiles) tile_ptr[t] = lower_bound_i32(pos_col, nnz, t * NT);
+        return;
+    }
     const int b = blockIdx.x, B = p.n_po + p.n_sp;
     float *q = Q + (size_t)b * ldq;
     if (b >= B) {
@@ -111,16 +121,120 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
     }
 }
 
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const double *__restrict__ partials, int n,
-                                                          double *__restrict__ out)
+__device__ __forceinline__ void loss_reduce_block(const double *__restrict__ partials, int n, double *__restrict__ out)
 {
     __shared__ double red[4];
+    const int nw = blockDim.x >> 6;
     double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += partials[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < nw; ++i) t += red[i];
+        out[0] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const double *__restrict__ partials, int n,
+                                                          double *__restrict__ out)
+{
+    loss_reduce_block(partials, n, out);
+}
+
+__device__ __forceinline__ float4 keep_mult4(const DropDev &dr, uint32_t pos, int k, int d)
+{
+    if (!dr.enabled) return make_float4(1.f, 1.f, 1.f, 1.f);
+    const uint32_t nib = (drop_keep8(dr, pos, k >> 3, d) >> (k & 4)) & 15u;
+    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+    apply_keep4(m, nib, dr.scale);
+    return m;
+}
+
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c)
+{
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 f4neg(float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+__device__ __forceinline__ void atomic_add4(float *p, float4 v)
+{
+    atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+// 8 batch rows per workgroup, 32 lanes per row, float4 per lane (needs d % 8 == 0 for ComplEx, d % 4 == 0 for
+// DistMult).  The last workgroup (blockIdx.x == gridDim.x - 1) instead sums the loss partials.
+__global__ __launch_bounds__(256) void prefix_backward_vec_kernel(const float *__restrict__ E, const float *__restrict__ R,
+                                                                  int d, int scorer, const PrefixDev p,
+                                                                  const float *__restrict__ slab, int nsplit, int Bpad,
+                                                                  int ldq, float *__restrict__ dE, float *__restrict__ dR,
+                                                                  const double *__restrict__ loss_partials,
+                                                                  int n_partials, double *__restrict__ loss_out)
+{
+    if (blockIdx.x == gridDim.x - 1) {
+        loss_reduce_block(loss_partials, n_partials, loss_out);
+        return;
+    }
+    const int B = p.n_po + p.n_sp;
+    const int b = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), lane = threadIdx.x & 31;
+    if (b >= B) return;
+    const RowSrc rs = row_source(p, b);
+    const DropDev &de = rs.sp ? p.drop_sp_ent : p.drop_po_ent;
+    const DropDev &dr = rs.sp ? p.drop_sp_rel : p.drop_po_rel;
+    const float *e = E + rs.ent * d, *r = R + rs.rel * d;
+    float *ge = dE + rs.ent * d, *gr = dR + rs.rel * d;
+    const size_t split_stride = (size_t)Bpad * ldq;
+    const float *sl = slab + (size_t)b * ldq;
+    auto dq_sum = [&](int k) {          // 8 independent loads in flight per lane (latency-bound otherwise)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sidx = 0;
+        for (; sidx + 8 <= nsplit; sidx += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(sl + (sidx + u) * split_stride + k);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; sidx < nsplit; ++sidx) {
+            const float4 v = *reinterpret_cast<const float4 *>(sl + sidx * split_stride + k);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        return acc;
+    };
+    if (scorer == SC_DISTMULT) {
+        for (int k = 4 * lane; k < d; k += 128) {
+            const float4 dq = dq_sum(k);
+            const float4 me = keep_mult4(de, rs.pos, k, d), mr = keep_mult4(dr, rs.pos, k, d);
+            const float4 ev = f4mul(*reinterpret_cast<const float4 *>(e + k), me);
+            const float4 rv = f4mul(*reinterpret_cast<const float4 *>(r + k), mr);
+            atomic_add4(ge + k, f4mul(f4mul(dq, rv), me));
+            atomic_add4(gr + k, f4mul(f4mul(dq, ev), mr));
+        }
+        return;
+    }
+    const int h = d >> 1;
+    for (int k = 4 * lane; k < h; k += 128) {
+        const float4 q1 = dq_sum(k), q2 = dq_sum(h + k);
+        const float4 me1 = keep_mult4(de, rs.pos, k, d), me2 = keep_mult4(de, rs.pos, h + k, d);
+        const float4 mr1 = keep_mult4(dr, rs.pos, k, d), mr2 = keep_mult4(dr, rs.pos, h + k, d);
+        const float4 e1 = f4mul(*reinterpret_cast<const float4 *>(e + k), me1);
+        const float4 e2 = f4mul(*reinterpret_cast<const float4 *>(e + h + k), me2);
+        const float4 r1 = f4mul(*reinterpret_cast<const float4 *>(r + k), mr1);
+        const float4 r2 = f4mul(*reinterpret_cast<const float4 *>(r + h + k), mr2);
+        float4 de1, de2, dr1, dr2;
+        if (rs.sp) {
+            de1 = f4fma(q1, r1, f4mul(q2, r2));           de2 = f4fma(q2, r1, f4neg(f4mul(q1, r2)));
+            dr1 = f4fma(q1, e1, f4mul(q2, e2));           dr2 = f4fma(q2, e1, f4neg(f4mul(q1, e2)));
+        } else {
+            de1 = f4fma(q1, r1, f4neg(f4mul(q2, r2)));    de2 = f4fma(q1, r2, f4mul(q2, r1));
+            dr1 = f4fma(q1, e1, f4mul(q2, e2));           dr2 = f4fma(q1, e2, f4neg(f4mul(q2, e1)));
+        }
+        atomic_add4(ge + k, f4mul(de1, me1));
+        atomic_add4(ge + h + k, f4mul(de2, me2));
+        atomic_add4(gr + k, f4mul(dr1, mr1));
+        atomic_add4(gr + h + k, f4mul(dr2, mr2));
+    }
 }
 
 __global__ __launch_bounds__(256) void kl_count_pos_kernel(const int32_t *__restrict__ pos_row, int nnz,
@@ -173,6 +287,43 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, flo
         p[i] = p[i] - lr * (gj / (sqrtf(sum[i]) + eps));
         if (zero_grad) g[i] = 0.f;
     }
+}
+
+struct AdagradSeg { float *p, *g, *s; int64_t n; };
+
+__device__ __forceinline__ void adagrad_sweep(const AdagradSeg sg, float lr, float wd, float eps, int zero_grad,
+                                              int64_t first, int64_t stride)
+{
+    const int64_t n4 = sg.n >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(sg.p), *g4 = reinterpret_cast<float4 *>(sg.g), *s4 = reinterpret_cast<float4 *>(sg.s);
+    for (int64_t i = first; i < n4; i += stride) {
+        float4 pv = p4[i], gv = g4[i], sv = s4[i];
+        float *pp = &pv.x, *gg = &gv.x, *ss = &sv.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gj = fmaf(wd, pp[j], gg[j]);
+            ss[j] = fmaf(gj, gj, ss[j]);
+            pp[j] = pp[j] - lr * (gj / (sqrtf(ss[j]) + eps));
+        }
+        p4[i] = pv;
+        s4[i] = sv;
+        if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (first < (sg.n & 3)) {
+        const int64_t i = (n4 << 2) + first;
+        const float gj = fmaf(wd, sg.p[i], sg.g[i]);
+        sg.s[i] = fmaf(gj, gj, sg.s[i]);
+        sg.p[i] = sg.p[i] - lr * (gj / (sqrtf(sg.s[i]) + eps));
+        if (zero_grad) sg.g[i] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void adagrad2_kernel(const AdagradSeg a, const AdagradSeg b, float lr, float wd,
+                                                       float eps, int zero_grad)
+{
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    adagrad_sweep(a, lr, wd, eps, zero_grad, first, stride);
+    adagrad_sweep(b, lr, wd, eps, zero_grad, first, stride);
 }
 
 constexpr int RANK_GROUPS = 8;
@@ -236,27 +387,32 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
 
 // ---- launchers -----------------------------------------------------------------------------------------
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
-                                 int ldq, int Bpad, hipStream_t st)
+                                 int ldq, int Bpad, const int32_t *pos_col, int nnz, int32_t *tile_ptr, int tiles,
+                                 hipStream_t st)
 {
     if (Bpad <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encode_queries_kernel, dim3(Bpad), dim3(128), 0, st, E, R, d, scorer, p, Q, ldq);
+    const int extra = tile_ptr ? (tiles + 1 + 127) / 128 : 0;
+    hipLaunchKernelGGL(encode_queries_kernel, dim3(Bpad + extra), dim3(128), 0, st, E, R, d, scorer, p, Q, ldq, Bpad,
+                       pos_col, nnz, tile_ptr, tiles);
     return hipGetLastError();
 }
 
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
                                   const float *slab, int nsplit, int Bpad, int ldq, float *dE, float *dR,
-                                  hipStream_t st)
+                                  const double *loss_partials, int n_partials, double *loss_out, hipStream_t st)
 {
     const int B = p.n_po + p.n_sp;
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(prefix_backward_kernel, dim3(B), dim3(128), 0, st, E, R, d, scorer, p, slab, nsplit, Bpad, ldq,
-                       dE, dR);
-    return hipGetLastError();
-}
-
-hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st)
-{
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, partials, n, loss_out);
+    const bool vec = scorer == SC_DISTMULT ? (d % 4 == 0) : (d % 8 == 0);
+    if (vec) {
+        // 2 batch rows per 64-thread workgroup (the loss-reduction workgroup also runs with 64 threads)
+        hipLaunchKernelGGL(prefix_backward_vec_kernel, dim3((B + 1) / 2 + 1), dim3(64), 0, st, E, R, d, scorer, p, slab,
+                           nsplit, Bpad, ldq, dE, dR, loss_partials, n_partials, loss_out);
+    } else {
+        hipLaunchKernelGGL(prefix_backward_kernel, dim3(B), dim3(128), 0, st, E, R, d, scorer, p, slab, nsplit, Bpad, ldq,
+                           dE, dR);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_partials, n_partials, loss_out);
+    }
     return hipGetLastError();
 }
 
@@ -277,6 +433,17 @@ hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, f
     const int64_t n4 = (n + 3) / 4;
     const int blocks = (int)min((int64_t)2048, (n4 + 255) / 256);
     hipLaunchKernelGGL(adagrad_kernel, dim3(blocks), dim3(256), 0, st, p, g, sum, n, lr, wd, eps, zero_grad);
+    return hipGetLastError();
+}
+
+hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p1, float *g1, float *s1, int64_t n1,
+                           float lr, float wd, float eps, int zero_grad, hipStream_t st)
+{
+    const int64_t n4 = (std::max(n0, n1) + 3) / 4;
+    if (n4 <= 0) return hipSuccess;
+    const int blocks = (int)std::min((int64_t)2048, (n4 + 255) / 256);
+    const AdagradSeg a{p0, g0, s0, n0}, b{p1, g1, s1, n1};
+    hipLaunchKernelGGL(adagrad2_kernel, dim3(blocks), dim3(256), 0, st, a, b, lr, wd, eps, zero_grad);
     return hipGetLastError();
 }
 

@@ -161,7 +161,7 @@ class HotPath:
         return out
 
     def forward_backward(self, E, R, scorer, batch: PrefixBatch, dE, dR, loss="bce", label_smoothing=0.0,
-                         normalizer=None, loss_out=None, scores=None):
+                         normalizer=None, loss_out=None, scores=None, grads_zero=False):
         """Fused forward + loss + backward; accumulates into dE / dR; returns the summed loss as a
         device double[1] tensor (no host sync)."""
         pb, c, keep = self._batch(batch)
@@ -178,6 +178,7 @@ class HotPath:
         N.check(self.lib.okge_train_forward_backward(
             ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), ctypes.byref(pos),
             N.LOSSES[loss] if isinstance(loss, str) else int(loss), float(label_smoothing), float(normalizer),
+            N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0,
             loss_out.data_ptr(), dE.data_ptr(), dR.data_ptr(),
             None if scores is None else scores.data_ptr(), 0 if scores is None else scores.stride(0),
             ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_forward_backward")
@@ -188,6 +189,12 @@ class HotPath:
         N.check(self.lib.okge_adagrad_step(p.data_ptr(), g.data_ptr(), state_sum.data_ptr(), p.numel(), float(lr),
                                            float(weight_decay), float(eps), 1 if zero_grad else 0, self._stream()),
                 "okge_adagrad_step")
+
+    def adagrad2(self, p0, g0, s0, p1, g1, s1, lr, weight_decay=1e-10, eps=1e-8, zero_grad=True):
+        """Both tables in one launch."""
+        N.check(self.lib.okge_adagrad_step2(p0.data_ptr(), g0.data_ptr(), s0.data_ptr(), p0.numel(), p1.data_ptr(),
+                                            g1.data_ptr(), s1.data_ptr(), p1.numel(), float(lr), float(weight_decay),
+                                            float(eps), 1 if zero_grad else 0, self._stream()), "okge_adagrad_step2")
 
     def filtered_ranks(self, scores, filt_ptr, filt_col, row_ptr, grp_ptr, ids):
         """int64 ranks per answer group; all index arrays on the device (int64 ptr arrays, int32 ids)."""

@@ -27,6 +27,7 @@ class FusedTrainStep:
         self.dE, self.dR = torch.zeros_like(E), torch.zeros_like(R)       # dense .grad (model_config.sparse False)
         self.sumE, self.sumR = torch.zeros_like(E), torch.zeros_like(R)   # Adagrad state 'sum' (init 0)
         self.steps = 0
+        self._grads_zero = True           # fresh buffers; kept true by the zero_grad fused into Adagrad
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=E.device)
 
     def _set_dropout(self, batch: H.PrefixBatch, training=True):
@@ -44,15 +45,17 @@ class FusedTrainStep:
         self._set_dropout(batch)
         return self.engine.forward_backward(self.E, self.R, self.scorer, batch, self.dE, self.dR, loss=self.loss,
                                             label_smoothing=self.label_smoothing, normalizer=normalizer,
-                                            loss_out=self.loss_out)
+                                            loss_out=self.loss_out, grads_zero=self._grads_zero)
 
     def optimizer_step(self):
         """trainer.py:240-244: optimizer.step() then zero_grad() -- one sweep per table."""
-        self.engine.adagrad(self.E, self.dE, self.sumE, self.lr, self.weight_decay, self.eps, zero_grad=True)
-        self.engine.adagrad(self.R, self.dR, self.sumR, self.lr, self.weight_decay, self.eps, zero_grad=True)
+        self.engine.adagrad2(self.E, self.dE, self.sumE, self.R, self.dR, self.sumR, self.lr, self.weight_decay,
+                             self.eps, zero_grad=True)
 
     def step(self, batch: H.PrefixBatch, normalizer=None):
         self.steps += 1
         loss = self.forward_backward(batch, normalizer)
+        self._grads_zero = False
         self.optimizer_step()
+        self._grads_zero = True
         return loss

@@ -259,7 +259,7 @@ def metrics_from_ranks(ranks, row_ptr):
 
 # ------------------------------------------------------------------------------------------------
 # counter-based dropout masks (this build's replacement for torch's bernoulli_, SURVEY.md 'hard
-# parts'): Philox4x32-10, key = seed, counter = (row, column/4, stream, step).  Integer work ->
+# parts'): Philox4x32-10, key = seed, counter = (row, column/8, stream, step).  Integer work ->
 # the HIP kernels reproduce these masks bit for bit.
 # ------------------------------------------------------------------------------------------------
 _PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
@@ -285,20 +285,24 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def dropout_threshold(p):
-    """keep  <=>  u32 >= threshold, threshold = floor(p * 2^32) clipped to [0, 2^32-1]."""
-    return np.uint32(min(max(int(float(p) * 4294967296.0), 0), 4294967295))
+    """keep  <=>  u16 >= threshold, threshold = floor(p * 2^16) clipped to [0, 65535]."""
+    return np.uint32(min(max(int(float(p) * 65536.0), 0), 65535))
 
 
 def dropout_keep_mask(seed, stream, step, nrows, d, p, row_keys=None):
-    """keep[row, k] for k < d.  counter = (row_key, k >> 2, stream, step); word k & 3 of the output.
+    """keep[row, k] for k < d.  One Philox4x32-10 call yields 8 uniform 16-bit numbers:
+    counter = (row_key, k >> 3, stream, step); element k uses word (k & 7) >> 1, low half for even k,
+    high half for odd k.  keep <=> that u16 >= floor(p * 65536).
 
     row_key defaults to the row's position in the list (candidate position / batch row).
     """
     rows = np.arange(nrows, dtype=np.uint32) if row_keys is None else np.asarray(row_keys, dtype=np.uint32)
-    nq = (d + 3) // 4
-    q = np.arange(nq, dtype=np.uint32)
+    no = (d + 7) // 8
+    o = np.arange(no, dtype=np.uint32)
     k0 = np.uint32(int(seed) & 0xFFFFFFFF)
     k1 = np.uint32((int(seed) >> 32) & 0xFFFFFFFF)
-    w = philox4x32_10(rows[:, None], q[None, :], np.uint32(stream), np.uint32(int(step) & 0xFFFFFFFF), k0, k1)
-    u = np.stack(w, axis=-1).reshape(len(rows), nq * 4)[:, :d]
+    w = philox4x32_10(rows[:, None], o[None, :], np.uint32(stream), np.uint32(int(step) & 0xFFFFFFFF), k0, k1)
+    w = np.stack(w, axis=-1)                                   # [rows, no, 4] uint32
+    u16 = np.stack([w & np.uint32(0xFFFF), w >> np.uint32(16)], axis=-1)   # [rows, no, 4, 2]
+    u = u16.reshape(len(rows), no * 8)[:, :d]
     return u >= dropout_threshold(p)

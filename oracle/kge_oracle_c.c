@@ -67,19 +67,22 @@ void okge_oracle_philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
     }
 }
 
-/* keep[row][k] = word (k&3) of philox(counter = (row_key, k>>2, stream, step), key = seed) >= thr */
+/* keep[row][k]: philox(counter = (row_key, k>>3, stream, step), key = seed) gives 4 words = 8 u16;
+ * element k uses word (k&7)>>1, low half for even k, high half for odd k; keep <=> u16 >= floor(p*65536) */
 int okge_oracle_philox_keep(uint64_t seed, uint32_t stream, uint32_t step, int64_t nrows, int64_t d,
                             double p, const uint32_t *row_keys, uint8_t *keep)
 {
-    double t = p * 4294967296.0;
-    uint32_t thr = t <= 0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+    double t = p * 65536.0;
+    uint32_t thr = t <= 0 ? 0u : (t >= 65535.0 ? 65535u : (uint32_t)t);
     for (int64_t r = 0; r < nrows; ++r) {
         uint32_t key = row_keys ? row_keys[r] : (uint32_t)r;
-        for (int64_t q = 0; q * 4 < d; ++q) {
-            uint32_t c[4] = { key, (uint32_t)q, stream, step };
+        for (int64_t o = 0; o * 8 < d; ++o) {
+            uint32_t c[4] = { key, (uint32_t)o, stream, step };
             okge_oracle_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-            for (int w = 0; w < 4 && q * 4 + w < d; ++w)
-                keep[r * d + q * 4 + w] = c[w] >= thr;
+            for (int e = 0; e < 8 && o * 8 + e < d; ++e) {
+                uint32_t u16 = (c[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+                keep[r * d + o * 8 + e] = u16 >= thr;
+            }
         }
     }
     return 0;

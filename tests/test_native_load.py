@@ -14,7 +14,7 @@ def test_header_symbols_exported():
         _native.build_native()
     L = _native.lib()
     header = open(os.path.join(ROOT, "include", "okge.h")).read()
-    declared = set(re.findall(r"\b(okge_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(okge_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
     for sym in declared:
         assert getattr(L, sym) is not None
