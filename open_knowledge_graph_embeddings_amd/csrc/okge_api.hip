@@ -111,6 +111,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct Geometry {
     int    B, N, d, Bpad, D16, KB, LDK, ldq, ldg, tiles, b_split, b_per_block, nsplit;
+    int    tile_w, ktiles;      // fused train kernel: tile width (32 or 64 candidates) and tile count
     size_t off_Q, off_tptr, off_GT, off_Cm, off_slab, off_loss, off_stats, off_lse, off_ysum, total;
 };
 
@@ -135,9 +136,14 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.tiles = (N + NT - 1) / NT;
     g.ldg = g.tiles * NT;
     const int bblks = g.Bpad / BC;
-    // fill the 256 CUs: if there are few candidate tiles, split the batch rows across blockIdx.y
+    // fused train kernel: 32-candidate tiles, two workgroups per CU; an even tile count so that every
+    // 64-candidate chunk dq_kernel reads has been written
+    g.tile_w = 32;
+    g.ktiles = 2 * g.tiles;
+    const int slots = 512;
+    // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y
     int bs = 1;
-    if (g.tiles < 192) bs = std::min(bblks, (256 + g.tiles - 1) / g.tiles);
+    if (g.ktiles < slots * 3 / 4) bs = std::min(bblks, (slots + g.ktiles - 1) / g.ktiles);
     bs = std::max(1, env_int("OKGE_B_SPLIT", bs));
     bs = std::min(bs, bblks);
     g.b_per_block = (bblks + bs - 1) / bs * BC;
@@ -150,11 +156,11 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.nsplit = ns;
     size_t off = 0;
     g.off_Q = off;     off += align_up((size_t)g.Bpad * g.ldq * sizeof(float), 256);
-    g.off_tptr = off;  off += align_up((size_t)(g.tiles + 1) * sizeof(int32_t), 256);
+    g.off_tptr = off;  off += align_up((size_t)(2 * g.tiles + 1) * sizeof(int32_t), 256);
     g.off_GT = off;    off += align_up((size_t)g.Bpad * g.ldg * sizeof(float), 256);
     g.off_Cm = off;    off += align_up((size_t)g.tiles * NT * g.D16 * sizeof(float), 256);
     g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
-    g.off_loss = off;  off += align_up((size_t)g.tiles * g.b_split * sizeof(double), 256);
+    g.off_loss = off;  off += align_up((size_t)2 * g.tiles * g.b_split * sizeof(double), 256);
     g.off_stats = off; off += align_up((size_t)g.tiles * g.Bpad * 2 * sizeof(float), 256);
     g.off_lse = off;   off += align_up((size_t)g.Bpad * sizeof(float), 256);
     g.off_ysum = off;  off += align_up((size_t)g.Bpad * sizeof(float), 256);
@@ -222,7 +228,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     {
         ScopedTimer tm("encode_queries", st);
         hipError_t e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q),
-                                             g.ldq, g.Bpad, nullptr, 0, nullptr, g.tiles, st);
+                                             g.ldq, g.Bpad, nullptr, 0, nullptr, g.tiles, NT, st);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
@@ -262,7 +268,8 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     {
         ScopedTimer tm("encode_queries", st);
         e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
-                                  g.Bpad, pos->col, pos->nnz, reinterpret_cast<int32_t *>(ws + g.off_tptr), g.tiles, st);
+                                  g.Bpad, pos->col, pos->nnz, reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles,
+                                  g.tile_w, st);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
@@ -270,6 +277,8 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     a.pos_col = pos->col; a.pos_row = pos->row; a.nnz = pos->nnz;
     a.tile_ptr = reinterpret_cast<const int32_t *>(ws + g.off_tptr);
     a.grads_zero = (flags & OKGE_TRAIN_GRADS_ZERO) ? 1 : 0;
+    a.stagger = env_int("OKGE_STAGGER", 0);
+    a.ablate = env_int("OKGE_ABLATE", 0);
     a.G = reinterpret_cast<float *>(ws + g.off_GT);
     a.Cm = reinterpret_cast<float *>(ws + g.off_Cm);
     a.dE = dE;
@@ -313,7 +322,8 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
 #endif
     {
         ScopedTimer tm("fused_tile_train", st);
-        e = launch_fused(loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE, a, g.tiles, g.b_split, st);
+        const int mode = loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE;
+        e = launch_fused32(mode, a, g.ktiles, g.b_split, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
     }
     DqArgs q;
@@ -330,7 +340,7 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     {
         ScopedTimer tm("prefix_backward", st);      // + the deterministic loss reduction (one extra workgroup)
         e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, dE, dR,
-                                   a.loss_partial, g.tiles * g.b_split, loss_out, st);
+                                   a.loss_partial, g.ktiles * g.b_split, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
     }
     return OKGE_OK;

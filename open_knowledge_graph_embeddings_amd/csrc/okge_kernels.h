@@ -10,6 +10,7 @@ constexpr int NT = 64;             // candidate rows per tile
 constexpr int BC = 64;             // batch rows per chunk
 constexpr int LDG = 68;            // leading dimension of the 64x64 G / X tile in LDS (4*odd)
 constexpr int FUSED_THREADS = 256; // 4 waves, one per SIMD
+constexpr int POS_CACHE = 512;     // positives of one candidate tile cached in LDS (more spill to global reads)
 
 enum { MODE_TRAIN_BCE = 0, MODE_SCORE = 1, MODE_STATS = 2, MODE_TRAIN_KL = 3 };
 enum { LOSS_BCE = 0, LOSS_KL = 1 };
@@ -33,6 +34,9 @@ struct FusedArgs {
     DropDev        drop_c;
     int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero;
     float          y_pos, y_neg, inv_norm;
+    int32_t        stagger;    // s_sleep units (64 clk) the second-resident workgroups wait before starting
+    int32_t        ablate;     // diagnostic (OKGE_ABLATE): bit0 no score product, 1 no loss math, 2 no G store,
+                               // 3 no dC product, 4 no candidate dropout/Cm store, 5 no dE write-back, 6 no Q staging
 };
 
 struct DqArgs {
@@ -52,10 +56,12 @@ size_t     fused_shmem_bytes(int LDK);
 size_t     dq_shmem_bytes(int LDK);
 hipError_t launch_fused(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st);
+size_t     fused32_shmem_bytes(int LDK);
+hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, const int32_t *pos_col, int nnz, int32_t *tile_ptr, int tiles,
-                                 hipStream_t st);
+                                 int tile_w, hipStream_t st);
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
                                   const float *slab, int nsplit, int Bpad, int ldq, float *dE, float *dR,
                                   const double *loss_partials, int n_partials, double *loss_out, hipStream_t st);

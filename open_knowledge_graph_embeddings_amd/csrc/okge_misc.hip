@@ -34,12 +34,12 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
                                                              int d, int scorer, const PrefixDev p,
                                                              float *__restrict__ Q, int ldq, int Bpad,
                                                              const int32_t *__restrict__ pos_col, int nnz,
-                                                             int32_t *__restrict__ tile_ptr, int tiles)
+                                                             int32_t *__restrict__ tile_ptr, int tiles, int tile_w)
 {
     if ((int)blockIdx.x >= Bpad) {
         // extra workgroups: offsets of each candidate tile's positives in the column-sorted coordinate list
         const int t = ((int)blockIdx.x - Bpad) * 128 + threadIdx.x;
-        if (t <= tiles) tile_ptr[t] = lower_bound_i32(pos_col, nnz, t * NT);
+        if (t <= tiles) tile_ptr[t] = lower_bound_i32(pos_col, nnz, t * tile_w);
         return;
     }
     const int b = blockIdx.x, B = p.n_po + p.n_sp;
@@ -388,12 +388,12 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
 // ---- launchers -----------------------------------------------------------------------------------------
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, const int32_t *pos_col, int nnz, int32_t *tile_ptr, int tiles,
-                                 hipStream_t st)
+                                 int tile_w, hipStream_t st)
 {
     if (Bpad <= 0) return hipSuccess;
     const int extra = tile_ptr ? (tiles + 1 + 127) / 128 : 0;
     hipLaunchKernelGGL(encode_queries_kernel, dim3(Bpad + extra), dim3(128), 0, st, E, R, d, scorer, p, Q, ldq, Bpad,
-                       pos_col, nnz, tile_ptr, tiles);
+                       pos_col, nnz, tile_ptr, tiles, tile_w);
     return hipGetLastError();
 }
 

@@ -1,0 +1,388 @@
+// fused_tile32_kernel<KB, MODE>: the fused score -> loss -> dCand tile kernel (see okge_train.hip) re-cut so that
+// TWO workgroups are resident per CU: 32 candidates x 32 batch rows per step, ~60 KB LDS, <= 256 registers.
+// With one wave per SIMD (the 64x64 cut) every non-MFMA phase -- candidate gather, loss epilogue, LDS staging,
+// gradient write-back -- leaves the matrix pipe idle; with two independent workgroups per CU the hardware
+// interleaves one workgroup's MFMA phase with the other's VALU / memory phases.
+//
+// Wave roles (4 waves): nbk = w & 1 (16-candidate block), half = w >> 1.
+//   score product : wave computes the 16x16 block X[b-block half][n-block nbk] (two accumulator chains over k).
+//   dC product    : wave accumulates dC[n-block nbk][all 16*KB columns] over batch rows 16*half .. 16*half+15 of the
+//                   chunk; the two halves' partial sums are added in the write-back epilogue.
+// Register chaining: the MFMA result layout of the score block (lane column = candidate, register i of slot s =
+// batch row 4s+i) is exactly the A-operand layout the dC product needs (M index = candidate, contraction slot s,
+// step i = batch row 4s+i), so G = dLoss/dX never goes through LDS and no barrier separates the two products.
+// G leaves for dq_kernel straight from registers in a blocked layout (one float4 per lane, 1 KB per wave):
+//   G_blk[(T * nJ + J) * 16 + (t&1)*8 + (j&1)*4 + w][lane]   T = t>>1 (64-candidate chunk), J = j>>1 (64-row block)
+#include <cstdio>
+#include <cstdlib>
+
+#include "okge_device.h"
+#include "okge_kernels.h"
+
+namespace okge {
+
+constexpr int NT32 = 32, BC32 = 32;
+
+template <int KB, int MODE>
+__global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const FusedArgs a)
+{
+#ifdef OKGE_STAMPS
+    unsigned long long wg_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
+    int tl_n = 0;
+#define TL_STAMP()                                                                                              \
+    do {                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+        unsigned long long t_;                                                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+        if (a.stamps_dbg && threadIdx.x == 0 && tl_n < 80)                                                      \
+            a.stamps_dbg[(size_t)gridDim.x * gridDim.y * 4 + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 80 + tl_n] = t_; \
+        ++tl_n;                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    } while (0)
+#else
+#define TL_STAMP() do { } while (0)
+#endif
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDK = lds_ld(16 * KB);
+    constexpr int KQ = KB / 4, KR = KB % 4;
+    constexpr int NO = 2 * KB, NOIT = (NO + 7) / 8;      // 8-column octets per row
+    constexpr int NQ = 4 * KB, NQIT = (NQ + 7) / 8;      // float4 per row
+    const int d = a.d;
+    float *Cs = reinterpret_cast<float *>(smem);              // [32][LDK]   (end: dC stage of half 1)
+    float *Qs = Cs + NT32 * LDK;                              // [32][LDK]   (end: dC stage of half 0)
+    uint32_t *ybits2 = reinterpret_cast<uint32_t *>(Qs + BC32 * LDK);    // [2][32] label bits, double-buffered by chunk
+    double *red = reinterpret_cast<double *>(ybits2 + 2 * BC32);         // [4]
+    uint8_t *keepb = reinterpret_cast<uint8_t *>(red + 4);               // [32][32] keep flags of the tile
+    uint32_t *posc = reinterpret_cast<uint32_t *>(keepb + NT32 * 32);    // [POS_CACHE] (row << 6 | col) of the tile
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, s = lane >> 4;
+    const int nbk = w & 1, half = w >> 1;
+    const int n0 = blockIdx.x * NT32;
+    const int b_begin = blockIdx.y * a.b_per_block;
+    const int b_end = min(a.B, b_begin + a.b_per_block);
+    const bool vec_ok = (d & 3) == 0;
+    const int r8 = tid >> 3, q8 = tid & 7;                    // staging role: row r8, column group q8
+
+    // ---- register-staged query chunk (32 rows x 16*KB): thread holds float4 columns q8 + 8*it of row r8 ------
+    v4f qreg[NQIT];
+    auto fetch_chunk = [&](int b0) {
+        const int b = b0 + r8;
+        const float *src = a.Q + (size_t)b * a.ldq;
+#pragma unroll
+        for (int it = 0; it < NQIT; ++it) {
+            const int q = min(q8 + 8 * it, NQ - 1);
+            qreg[it] = (b < b_end) ? *reinterpret_cast<const v4f *>(src + 4 * q) : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch_chunk(b_begin);
+    // De-phase the two workgroups that share a CU (identical programs launched together otherwise run in
+    // lockstep: both in their MFMA phase, then both in their VALU/memory phase).  Speed only, never correctness.
+    {
+        const unsigned bid = blockIdx.x + blockIdx.y * gridDim.x;
+        const int mode = a.stagger >> 16, amount = a.stagger & 0xFFFF;
+        const bool late = mode == 0 ? bid >= 256 : mode == 1 ? (bid & 1) : mode == 2 ? ((bid >> 3) & 1) : ((bid >> 8) & 1);
+        if (amount > 0 && late)
+            for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+
+    // ---- candidate tile: gather, dropout, LDS; masked copy for dq_kernel ---------------------------------------
+    {
+        const int n = n0 + r8;
+        const bool valid = n < a.N;
+        int64_t cid = 0;
+        if (valid) cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
+        const float *row = a.E + cid * d;
+        float *cm = (blockIdx.y == 0) ? a.Cm + (size_t)n * (16 * KB) : nullptr;
+        v4f v0[NOIT], v1[NOIT];
+#pragma unroll
+        for (int it = 0; it < NOIT; ++it) {
+            const int o = q8 + 8 * it, k = 8 * o;
+            v0[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+            v1[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (o < NO && valid && k < d) {
+                if (vec_ok) {
+                    v0[it] = *reinterpret_cast<const v4f *>(row + k);
+                    if (k + 4 < d) v1[it] = *reinterpret_cast<const v4f *>(row + k + 4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (k + e < d) v0[it][e] = row[k + e];
+                        if (k + 4 + e < d) v1[it][e] = row[k + 4 + e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NOIT; ++it) {
+            const int o = q8 + 8 * it, k = 8 * o;
+            if (o < NO) {
+                uint32_t bits = 0xFFu;
+                if (a.drop_c.enabled && !(a.ablate & 16)) {
+                    bits = (valid && k < d) ? drop_keep8(a.drop_c, (uint32_t)n, o, d) : 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v0[it][e] *= (bits >> e & 1u) ? a.drop_c.scale : 0.f;
+                        v1[it][e] *= (bits >> (4 + e) & 1u) ? a.drop_c.scale : 0.f;
+                    }
+                }
+                *reinterpret_cast<v4f *>(Cs + r8 * LDK + k) = v0[it];
+                *reinterpret_cast<v4f *>(Cs + r8 * LDK + k + 4) = v1[it];
+                keepb[r8 * 32 + o] = (uint8_t)bits;
+                if (cm && !(a.ablate & 16)) {
+                    *reinterpret_cast<v4f *>(cm + k) = v0[it];
+                    *reinterpret_cast<v4f *>(cm + k + 4) = v1[it];
+                }
+            }
+        }
+    }
+    if (tid < 2 * BC32) ybits2[tid] = 0u;
+    // positives of this tile: cached in LDS once (a global re-read per chunk costs an L2 round trip each time)
+    const int pos_lo = a.tile_ptr[blockIdx.x], pos_hi = a.tile_ptr[blockIdx.x + 1];
+    const int pos_cached = min(pos_hi - pos_lo, POS_CACHE);
+    for (int i = tid; i < pos_cached; i += FUSED_THREADS)
+        posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - n0);
+    __syncthreads();
+
+    v4f dc[KB];                                      // dC[n = 16nbk + 4s + i][k = grad col(kbi, c)], rows of this half
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) dc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+
+    int par = 0;
+    for (int b0 = b_begin; b0 < b_end; b0 += BC32, par ^= 1) {
+        // ---- phase A: park the prefetched chunk, set label bits, prefetch the next chunk ------------------------
+        // (no barrier separates a wave's epilogue from its dC product any more, so the label bits are double-
+        //  buffered: this chunk's buffer was cleared one chunk ago, the previous chunk's buffer is cleared now)
+        uint32_t *ybits = ybits2 + par * BC32;
+        if (tid < BC32) ybits2[(par ^ 1) * BC32 + tid] = 0u;
+        if (!(a.ablate & 64)) {
+#pragma unroll
+            for (int it = 0; it < NQIT; ++it) {
+                const int q = q8 + 8 * it;
+                if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
+            }
+        }
+        for (int i = tid; i < pos_cached; i += FUSED_THREADS) {
+            const uint32_t v = posc[i];
+            const int row = (int)(v >> 6) - b0;
+            if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (v & 63u));
+        }
+        for (int p = pos_lo + POS_CACHE + tid; p < pos_hi; p += FUSED_THREADS) {      // overflow: rare
+            const int row = a.pos_row[p] - b0;
+            if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (a.pos_col[p] - n0));
+        }
+        if (b0 + BC32 < b_end && !(a.ablate & 64)) fetch_chunk(b0 + BC32);
+        __syncthreads();
+
+        TL_STAMP();   // [0] start of score product
+        // ---- phase B: X block (rows 16*half + 4s + i, columns 16*nbk + c) --------------------------------------
+        v4f x0 = (v4f){0.f, 0.f, 0.f, 0.f}, x1 = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (!(a.ablate & 1)) {
+            const float *qa = Qs + (16 * half + c) * LDK + 4 * s;
+            const float *cb = Cs + (16 * nbk + c) * LDK + 4 * s;
+#pragma unroll
+            for (int r = 0; r < KB; ++r) {
+                const v4f av = *reinterpret_cast<const v4f *>(qa + 16 * r);
+                const v4f bv = *reinterpret_cast<const v4f *>(cb + 16 * r);
+                x0 = mfma16(av[0], bv[0], x0);
+                x1 = mfma16(av[1], bv[1], x1);
+                x0 = mfma16(av[2], bv[2], x0);
+                x1 = mfma16(av[3], bv[3], x1);
+            }
+        }
+        const v4f x = x0 + x1;
+        TL_STAMP();   // [1] end of score product
+
+        // ---- loss epilogue: G = dLoss/dX / normalizer, kept in registers --------------------------------------
+        v4f g4;
+        {
+            constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+            const int nl = 16 * nbk + c;
+            const bool nvalid = n0 + nl < a.N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bl = 16 * half + 4 * s + i;
+                const float xv = x[i];
+                const bool valid = nvalid && (b0 + bl < b_end);
+                const bool pos = (ybits[bl] >> nl) & 1u;
+                float g, l;
+                if (a.ablate & 2) {
+                    g = xv; l = 0.f;
+                } else if (MODE == MODE_TRAIN_BCE) {
+                    const float y = pos ? a.y_pos : a.y_neg;
+                    const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * LOG2E);
+                    const float ope = 1.f + e;
+                    const float rcp = __builtin_amdgcn_rcpf(ope);
+                    const float sig = xv >= 0.f ? rcp : e * rcp;
+                    l = fmaxf(xv, 0.f) - xv * y + __builtin_amdgcn_logf(ope) * LN2;
+                    g = sig - y;
+                } else {
+                    const int b = min(b0 + bl, a.B - 1);
+                    const float lsm = xv - a.row_lse[b];
+                    l = pos ? -lsm : 0.f;
+                    g = __builtin_amdgcn_exp2f(lsm * LOG2E) * a.row_ysum[b] - (pos ? 1.f : 0.f);
+                }
+                lsum += valid ? l : 0.f;
+                g4[i] = valid ? g * a.inv_norm : 0.f;
+            }
+        }
+        // ---- G block -> HBM for dq_kernel (blocked layout, 1 KB per wave, no LDS) --------------------------------
+        if (!(a.ablate & 4)) {
+            const int t = blockIdx.x, j = b0 >> 5;
+            const size_t blk = ((size_t)(t >> 1) * (a.Bpad >> 6) + (j >> 1)) * 16 + (t & 1) * 8 + (j & 1) * 4 + w;
+            *reinterpret_cast<v4f *>(a.G + (blk * 64 + lane) * 4) = g4;
+        }
+        TL_STAMP();   // [2] start of dC product
+        // ---- dC += G^T . Q over this wave's 16 batch rows: A operand straight from g4 ----------------------------
+        if (!(a.ablate & 8)) {
+            // slot s, step t  <->  batch row 16*half + 4s + t ; A = G[row][n = 16nbk + c] = g4[t], B = Q[row][columns]
+            const float *qb = Qs + (16 * half + 4 * s) * LDK;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float av = g4[t];
+                const float *brow = qb + t * LDK;
+#pragma unroll
+                for (int kq = 0; kq < KQ; ++kq) {
+                    const v4f b4 = *reinterpret_cast<const v4f *>(brow + 64 * kq + 4 * c);
+                    dc[4 * kq + 0] = mfma16(av, b4[0], dc[4 * kq + 0]);
+                    dc[4 * kq + 1] = mfma16(av, b4[1], dc[4 * kq + 1]);
+                    dc[4 * kq + 2] = mfma16(av, b4[2], dc[4 * kq + 2]);
+                    dc[4 * kq + 3] = mfma16(av, b4[3], dc[4 * kq + 3]);
+                }
+#pragma unroll
+                for (int r = 0; r < KR; ++r)
+                    dc[4 * KQ + r] = mfma16(av, brow[64 * KQ + 16 * r + c], dc[4 * KQ + r]);
+            }
+        }
+        TL_STAMP();   // [3] end of dC product
+        __syncthreads();
+    }
+
+    // ---- write-back: both halves stage their partial dC (half 0 -> Qs, half 1 -> Cs), then rows are summed,
+    //      masked with the cached dropout flags and added into dE -------------------------------------------------
+    {
+        float *stage = half == 0 ? Qs : Cs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *srow = stage + (16 * nbk + 4 * s + i) * LDK;
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq)
+                *reinterpret_cast<v4f *>(srow + 64 * kq + 4 * c) =
+                    (v4f){dc[4 * kq][i], dc[4 * kq + 1][i], dc[4 * kq + 2][i], dc[4 * kq + 3][i]};
+#pragma unroll
+            for (int r = 0; r < KR; ++r) srow[64 * KQ + 16 * r + c] = dc[4 * KQ + r][i];
+        }
+        const double ls = wave_sum((double)lsum);
+        if (lane == 0) red[w] = ls;
+    }
+    __syncthreads();
+    if (tid == 0) a.loss_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (!(a.ablate & 32)) {
+        const int n = n0 + r8;
+        if (n < a.N) {
+            const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
+            float *drow = a.dE + cid * d;
+            const bool exclusive = gridDim.y == 1;
+#pragma unroll
+            for (int it = 0; it < NOIT; ++it) {
+                const int o = q8 + 8 * it, k = 8 * o;
+                if (o >= NO || k >= d) continue;
+                v4f v[2];
+                v[0] = *reinterpret_cast<const v4f *>(Qs + r8 * LDK + k) + *reinterpret_cast<const v4f *>(Cs + r8 * LDK + k);
+                v[1] = *reinterpret_cast<const v4f *>(Qs + r8 * LDK + k + 4) +
+                       *reinterpret_cast<const v4f *>(Cs + r8 * LDK + k + 4);
+                if (a.drop_c.enabled) {
+                    const uint32_t bits = keepb[r8 * 32 + o];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[0][e] *= (bits >> e & 1u) ? a.drop_c.scale : 0.f;
+                        v[1][e] *= (bits >> (4 + e) & 1u) ? a.drop_c.scale : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int kk = k + 4 * hh;
+                    if (kk >= d) continue;
+                    if (exclusive && vec_ok) {
+                        v4f o4 = v[hh];
+                        if (!a.grads_zero) o4 += *reinterpret_cast<const v4f *>(drow + kk);
+                        *reinterpret_cast<v4f *>(drow + kk) = o4;
+                    } else if (exclusive) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (kk + e < d) drow[kk + e] += v[hh][e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (kk + e < d) atomicAdd(drow + kk + e, v[hh][e]);
+                    }
+                }
+            }
+        }
+    }
+#ifdef OKGE_STAMPS
+    if (a.stamps_dbg && tid == 0) {
+        unsigned long long wg_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t1)::"memory");
+        unsigned long long *dst = a.stamps_dbg + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        dst[0] = wg_t0;
+        dst[1] = wg_t1;
+        dst[2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID
+        dst[3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID
+    }
+#endif
+}
+
+// ---- launcher ---------------------------------------------------------------------------------------------------
+size_t fused32_shmem_bytes(int LDK)
+{
+    return (size_t)(NT32 + BC32) * LDK * sizeof(float) + BC32 * sizeof(uint32_t) +
+           4 * sizeof(double) + NT32 * 32 + POS_CACHE * sizeof(uint32_t) + BC32 * sizeof(uint32_t);
+}
+
+template <int KB, int MODE>
+static hipError_t launch32_t(const FusedArgs &a, dim3 grid, size_t shmem, hipStream_t st)
+{
+    auto k = fused_tile32_kernel<KB, MODE>;
+    static size_t configured = 0;
+    if (shmem > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        configured = shmem;
+    }
+    if (std::getenv("OKGE_DEBUG")) {
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), FUSED_THREADS, shmem);
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k));
+        fprintf(stderr, "[okge] fused_tile32<%d>: occupancy %d blocks/CU (err %d), dyn LDS %zu, static LDS %zu, regs %d, grid %ux%u\n",
+                KB, nb, (int)e, shmem, (size_t)fa.sharedSizeBytes, fa.numRegs, grid.x, grid.y);
+    }
+    hipLaunchKernelGGL(k, grid, dim3(FUSED_THREADS), shmem, st, a);
+    return hipGetLastError();
+}
+
+template <int KB>
+static hipError_t launch32_m(int mode, const FusedArgs &a, dim3 grid, size_t shmem, hipStream_t st)
+{
+    return mode == MODE_TRAIN_KL ? launch32_t<KB, MODE_TRAIN_KL>(a, grid, shmem, st)
+                                 : launch32_t<KB, MODE_TRAIN_BCE>(a, grid, shmem, st);
+}
+
+// train modes only; grid_x = number of 32-candidate tiles (even, so every 64-wide chunk dq_kernel reads is written)
+hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st)
+{
+    const dim3 grid(grid_x, grid_y);
+    const size_t shmem = fused32_shmem_bytes(a.LDK);
+    switch (a.KB) {
+        case 4:  return launch32_m<4>(mode, a, grid, shmem, st);
+        case 8:  return launch32_m<8>(mode, a, grid, shmem, st);
+        case 13: return launch32_m<13>(mode, a, grid, shmem, st);
+        case 16: return launch32_m<16>(mode, a, grid, shmem, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace okge

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic (-DOKGE_STAMPS build): phase timeline of two fused_tile32 workgroups sharing a CU."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from open_knowledge_graph_embeddings_amd import _native
+_native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "libokge_hip_stamps.so")
+from open_knowledge_graph_embeddings_amd import synthetic
+from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+import bench
+
+w = synthetic.WORKLOADS["S-FB"]
+dev = torch.device("cuda:0")
+E, R = synthetic.make_tables(w)
+step = FusedTrainStep(torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev), w.scorer, lr=w.lr,
+                      input_dropout=w.input_dropout, seed=1)
+batches = [bench.to_dev_batch(synthetic.make_batch(w, seed=i), w, dev) for i in range(4)]
+tiles = 2 * ((w.N + 63) // 64)
+buf = torch.zeros(tiles * 4 + tiles * 80, dtype=torch.int64, device=dev)
+os.environ["OKGE_STAMPS_PTR"] = hex(buf.data_ptr())
+for i in range(3):
+    step.step(batches[i % 4])
+torch.cuda.synchronize()
+a = buf.cpu().numpy()
+head = a[: tiles * 4].reshape(-1, 4)
+tl = a[tiles * 4:].reshape(-1, 80)
+for wg in (int(sys.argv[1]) if len(sys.argv) > 1 else 5,):
+    A, B = wg, wg + 256
+    base = min(head[A, 0], head[B, 0])
+    print(f"WG {A}: start {head[A,0]-base} end {head[A,1]-base} | WG {B}: start {head[B,0]-base} end {head[B,1]-base}")
+    print("chunk |  A: P1start P1end P2start P2end (dur P1, P2) |  B: ...")
+    for ch in range(16):
+        ra = tl[A, 4 * ch: 4 * ch + 4] - base
+        rb = tl[B, 4 * ch: 4 * ch + 4] - base
+        print(f"{ch:3d}  A {ra[0]:7d} {ra[1]:7d} {ra[2]:7d} {ra[3]:7d} ({ra[1]-ra[0]:5d},{ra[3]-ra[2]:5d})   "
+              f"B {rb[0]:7d} {rb[1]:7d} {rb[2]:7d} {rb[3]:7d} ({rb[1]-rb[0]:5d},{rb[3]-rb[2]:5d})")
