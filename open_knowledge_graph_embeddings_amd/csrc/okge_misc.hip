@@ -163,9 +163,11 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v)
     atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
 }
 
-// 8 batch rows per workgroup, 32 lanes per row, float4 per lane (needs d % 8 == 0 for ComplEx, d % 4 == 0 for
-// DistMult).  The last workgroup (blockIdx.x == gridDim.x - 1) instead sums the loss partials.
-__global__ __launch_bounds__(256) void prefix_backward_vec_kernel(const float *__restrict__ E, const float *__restrict__ R,
+// One batch row per 128-thread workgroup: lane = (column group g = tid >> 2, split quarter sq = tid & 3).  The four
+// lanes of a column group sum disjoint quarters of the nsplit dQ slabs (all their loads are issued at once) and
+// combine with two shuffles; sq == 0 then applies the chain rule and scatters.  Needs d % 8 == 0 (ComplEx) or
+// d % 4 == 0 (DistMult).  The last workgroup (blockIdx.x == gridDim.x - 1) instead sums the loss partials.
+__global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                                   int d, int scorer, const PrefixDev p,
                                                                   const float *__restrict__ slab, int nsplit, int Bpad,
                                                                   int ldq, float *__restrict__ dE, float *__restrict__ dR,
@@ -176,9 +178,7 @@ __global__ __launch_bounds__(256) void prefix_backward_vec_kernel(const float *_
         loss_reduce_block(loss_partials, n_partials, loss_out);
         return;
     }
-    const int B = p.n_po + p.n_sp;
-    const int b = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5), lane = threadIdx.x & 31;
-    if (b >= B) return;
+    const int b = blockIdx.x, grp = threadIdx.x >> 2, sq = threadIdx.x & 3;
     const RowSrc rs = row_source(p, b);
     const DropDev &de = rs.sp ? p.drop_sp_ent : p.drop_po_ent;
     const DropDev &dr = rs.sp ? p.drop_sp_rel : p.drop_po_rel;
@@ -186,36 +186,51 @@ __global__ __launch_bounds__(256) void prefix_backward_vec_kernel(const float *_
     float *ge = dE + rs.ent * d, *gr = dR + rs.rel * d;
     const size_t split_stride = (size_t)Bpad * ldq;
     const float *sl = slab + (size_t)b * ldq;
-    auto dq_sum = [&](int k) {          // 8 independent loads in flight per lane (latency-bound otherwise)
+    const int s_lo = (nsplit * sq) >> 2, s_hi = (nsplit * (sq + 1)) >> 2;
+    auto dq_sum = [&](int k, bool active) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int sidx = 0;
-        for (; sidx + 8 <= nsplit; sidx += 8) {
-            float4 v[8];
+        if (active) {
+            int sidx = s_lo;
+            for (; sidx + 8 <= s_hi; sidx += 8) {
+                float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(sl + (sidx + u) * split_stride + k);
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(sl + (sidx + u) * split_stride + k);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; sidx < s_hi; ++sidx) {
+                const float4 v = *reinterpret_cast<const float4 *>(sl + sidx * split_stride + k);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
         }
-        for (; sidx < nsplit; ++sidx) {
-            const float4 v = *reinterpret_cast<const float4 *>(sl + sidx * split_stride + k);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+#pragma unroll
+        for (int o = 1; o < 4; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
+            acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
         }
         return acc;
     };
     if (scorer == SC_DISTMULT) {
-        for (int k = 4 * lane; k < d; k += 128) {
-            const float4 dq = dq_sum(k);
-            const float4 me = keep_mult4(de, rs.pos, k, d), mr = keep_mult4(dr, rs.pos, k, d);
-            const float4 ev = f4mul(*reinterpret_cast<const float4 *>(e + k), me);
-            const float4 rv = f4mul(*reinterpret_cast<const float4 *>(r + k), mr);
-            atomic_add4(ge + k, f4mul(f4mul(dq, rv), me));
-            atomic_add4(gr + k, f4mul(f4mul(dq, ev), mr));
+        for (int k0 = 0; k0 < d; k0 += 128) {
+            const int k = k0 + 4 * grp;
+            const bool act = k < d;
+            const float4 dq = dq_sum(act ? k : 0, act);
+            if (act && sq == 0) {
+                const float4 me = keep_mult4(de, rs.pos, k, d), mr = keep_mult4(dr, rs.pos, k, d);
+                const float4 ev = f4mul(*reinterpret_cast<const float4 *>(e + k), me);
+                const float4 rv = f4mul(*reinterpret_cast<const float4 *>(r + k), mr);
+                atomic_add4(ge + k, f4mul(f4mul(dq, rv), me));
+                atomic_add4(gr + k, f4mul(f4mul(dq, ev), mr));
+            }
         }
         return;
     }
     const int h = d >> 1;
-    for (int k = 4 * lane; k < h; k += 128) {
-        const float4 q1 = dq_sum(k), q2 = dq_sum(h + k);
+    for (int k0 = 0; k0 < h; k0 += 128) {
+        const int k = k0 + 4 * grp;
+        const bool act = k < h;
+        const float4 q1 = dq_sum(act ? k : 0, act), q2 = dq_sum(act ? h + k : 0, act);
+        if (!(act && sq == 0)) continue;
         const float4 me1 = keep_mult4(de, rs.pos, k, d), me2 = keep_mult4(de, rs.pos, h + k, d);
         const float4 mr1 = keep_mult4(dr, rs.pos, k, d), mr2 = keep_mult4(dr, rs.pos, h + k, d);
         const float4 e1 = f4mul(*reinterpret_cast<const float4 *>(e + k), me1);
@@ -405,8 +420,7 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
     if (B <= 0) return hipSuccess;
     const bool vec = scorer == SC_DISTMULT ? (d % 4 == 0) : (d % 8 == 0);
     if (vec) {
-        // 2 batch rows per 64-thread workgroup (the loss-reduction workgroup also runs with 64 threads)
-        hipLaunchKernelGGL(prefix_backward_vec_kernel, dim3((B + 1) / 2 + 1), dim3(64), 0, st, E, R, d, scorer, p, slab,
+        hipLaunchKernelGGL(prefix_backward_vec_kernel, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
                            nsplit, Bpad, ldq, dE, dR, loss_partials, n_partials, loss_out);
     } else {
         hipLaunchKernelGGL(prefix_backward_kernel, dim3(B), dim3(128), 0, st, E, R, d, scorer, p, slab, nsplit, Bpad, ldq,
@@ -431,7 +445,7 @@ hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, f
 {
     if (n <= 0) return hipSuccess;
     const int64_t n4 = (n + 3) / 4;
-    const int blocks = (int)min((int64_t)2048, (n4 + 255) / 256);
+    const int blocks = (int)min((int64_t)16384, (n4 + 255) / 256);
     hipLaunchKernelGGL(adagrad_kernel, dim3(blocks), dim3(256), 0, st, p, g, sum, n, lr, wd, eps, zero_grad);
     return hipGetLastError();
 }
@@ -441,7 +455,7 @@ hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p
 {
     const int64_t n4 = (std::max(n0, n1) + 3) / 4;
     if (n4 <= 0) return hipSuccess;
-    const int blocks = (int)std::min((int64_t)2048, (n4 + 255) / 256);
+    const int blocks = (int)std::min((int64_t)16384, (n4 + 255) / 256);
     const AdagradSeg a{p0, g0, s0, n0}, b{p1, g1, s1, n1};
     hipLaunchKernelGGL(adagrad2_kernel, dim3(blocks), dim3(256), 0, st, a, b, lr, wd, eps, zero_grad);
     return hipGetLastError();

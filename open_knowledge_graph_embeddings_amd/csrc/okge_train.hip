@@ -9,8 +9,8 @@
 //
 //   dq_kernel<KB>
 //     dQ = G . C : one workgroup per (64-row batch block, candidate range); partial slabs are summed by
-//     prefix_backward_kernel (okge_misc.hip).  G arrives in the blocked register layout fused_tile32_kernel
-//     writes (16 KB per 64x64 block) and is re-staged in LDS as G^T[n][b].
+//     prefix_backward_kernel (okge_misc.hip).  G arrives as 64x64 transposed blocks G^T[n][b] (16 KB each,
+//     written by fused_tile32_kernel straight from its registers) and is copied to LDS as is.
 //
 // KB = padded slot size / 16 is a compile-time constant so every operand read is unconditional.
 //
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
 }
 
 // ---- dQ = G . C over a candidate range -------------------------------------------------------------
-// G block (64 batch rows x 64 candidates, 16 KB in fused_tile32_kernel's blocked register layout) and masked
+// G^T block (64 candidates x 64 batch rows, 16 KB contiguous) and masked
 // candidate tile (64 x 16*KB) of one chunk -> registers
 template <int KB>
 __device__ __forceinline__ void dq_prefetch(v4f (&gv)[4], v4f (&cv)[4 * ((2 * KB + 7) / 8)],
@@ -264,7 +264,8 @@ __device__ __forceinline__ void dq_prefetch(v4f (&gv)[4], v4f (&cv)[4 * ((2 * KB
     }
 }
 
-constexpr int LDGT = 65;   // G^T tile leading dimension: odd, so rows 16 apart sit 16 banks apart (ds_read_b32)
+constexpr int LDGT = 68;   // G^T tile leading dimension (16-byte aligned rows; the A operand is one ds_read_b32 per 13 MFMAs,
+                           // so its 2-way conflict between slots 16 rows apart is irrelevant)
 
 template <int KB>
 __global__ __launch_bounds__(FUSED_THREADS) void dq_kernel(const DqArgs a)
@@ -293,16 +294,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void dq_kernel(const DqArgs a)
     auto g_block = [&](int ch) { return a.G + ((size_t)ch * nJ + bblk) * 4096; };
     if (ch_lo < ch_hi) dq_prefetch<KB>(gv, cv, g_block(ch_lo), a.Cm + (size_t)ch_lo * NT * (16 * KB), tid);
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
-        // G block -> G^T[n][b] in LDS.  float4 number f of the block: sub-block f>>6 = (t&1)*8 + (j&1)*4 + wave,
-        // source lane f&63 = (slot sK, column cK); its 4 values are batch rows 4*sK + i of the wave's 16-row block.
+        // G^T block -> LDS (float4 number f: candidate f >> 4, batch rows 4 * (f & 15) ..)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int f = tid + it * FUSED_THREADS, sub = f >> 6, ls = f & 63;
-            const int n = 32 * (sub >> 3) + 16 * (sub & 1) + (ls & 15);
-            const int b = 32 * ((sub >> 2) & 1) + 16 * ((sub >> 1) & 1) + 4 * (ls >> 4);
-            float *dst = Gt + n * LDGT + b;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dst[i] = gv[it][i];
+            const int f = tid + it * FUSED_THREADS;
+            *reinterpret_cast<v4f *>(Gt + (f >> 4) * LDGT + 4 * (f & 15)) = gv[it];
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -367,7 +363,7 @@ size_t fused_shmem_bytes(int LDK)
 
 size_t dq_shmem_bytes(int LDK)
 {
-    return (size_t)NT * LDK * sizeof(float) + (size_t)NT * 65 * sizeof(float);
+    return (size_t)NT * LDK * sizeof(float) + (size_t)NT * 68 * sizeof(float);
 }
 
 hipError_t launch_fused(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st)

@@ -11,8 +11,9 @@
 // Register chaining: the MFMA result layout of the score block (lane column = candidate, register i of slot s =
 // batch row 4s+i) is exactly the A-operand layout the dC product needs (M index = candidate, contraction slot s,
 // step i = batch row 4s+i), so G = dLoss/dX never goes through LDS and no barrier separates the two products.
-// G leaves for dq_kernel straight from registers in a blocked layout (one float4 per lane, 1 KB per wave):
-//   G_blk[(T * nJ + J) * 16 + (t&1)*8 + (j&1)*4 + w][lane]   T = t>>1 (64-candidate chunk), J = j>>1 (64-row block)
+// G leaves for dq_kernel straight from registers (one float4 per lane = 4 consecutive batch rows of one candidate)
+// as 64x64 transposed blocks  Gt[(T * nJ + J)][n_local (64)][b_local (64)],  T = 64-candidate chunk, J = 64-row block:
+// exactly the LDS image dq_kernel wants, so it stages the block with plain 16-byte copies.
 #include <cstdio>
 #include <cstdlib>
 
@@ -179,20 +180,38 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         // ---- phase B: X block (rows 16*half + 4s + i, columns 16*nbk + c) --------------------------------------
         v4f x0 = (v4f){0.f, 0.f, 0.f, 0.f}, x1 = (v4f){0.f, 0.f, 0.f, 0.f};
         if (!(a.ablate & 1)) {
+            // operands of round r+1 are requested before the 4 MFMAs of round r issue (LDS latency ~ one round)
             const float *qa = Qs + (16 * half + c) * LDK + 4 * s;
             const float *cb = Cs + (16 * nbk + c) * LDK + 4 * s;
+            v4f av = *reinterpret_cast<const v4f *>(qa), bv = *reinterpret_cast<const v4f *>(cb);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // round 0 operands
 #pragma unroll
             for (int r = 0; r < KB; ++r) {
-                const v4f av = *reinterpret_cast<const v4f *>(qa + 16 * r);
-                const v4f bv = *reinterpret_cast<const v4f *>(cb + 16 * r);
+                v4f an = av, bn = bv;
+                if (r + 1 < KB) {
+                    an = *reinterpret_cast<const v4f *>(qa + 16 * (r + 1));
+                    bn = *reinterpret_cast<const v4f *>(cb + 16 * (r + 1));
+                }
                 x0 = mfma16(av[0], bv[0], x0);
                 x1 = mfma16(av[1], bv[1], x1);
                 x0 = mfma16(av[2], bv[2], x0);
                 x1 = mfma16(av[3], bv[3], x1);
+                av = an; bv = bn;
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 ds_read (next round)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA   (this round)
             }
         }
         const v4f x = x0 + x1;
         TL_STAMP();   // [1] end of score product
+
+        // B operands (query rows) of the dC product's first step: requested now, consumed after the epilogue
+        const float *qb = Qs + (16 * half + 4 * s) * LDK;
+        v4f pb[KQ > 0 ? KQ : 1];
+        float pr[KR > 0 ? KR : 1];
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) pb[kq] = *reinterpret_cast<const v4f *>(qb + 64 * kq + 4 * c);
+#pragma unroll
+        for (int r = 0; r < KR; ++r) pr[r] = qb[64 * KQ + 16 * r + c];
 
         // ---- loss epilogue: G = dLoss/dX / normalizer, kept in registers --------------------------------------
         v4f g4;
@@ -227,32 +246,46 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
                 g4[i] = valid ? g * a.inv_norm : 0.f;
             }
         }
-        // ---- G block -> HBM for dq_kernel (blocked layout, 1 KB per wave, no LDS) --------------------------------
+        // ---- G block -> HBM for dq_kernel: Gt[T][J][n_local][b_local], 4 consecutive batch rows per lane ----------
         if (!(a.ablate & 4)) {
             const int t = blockIdx.x, j = b0 >> 5;
-            const size_t blk = ((size_t)(t >> 1) * (a.Bpad >> 6) + (j >> 1)) * 16 + (t & 1) * 8 + (j & 1) * 4 + w;
-            *reinterpret_cast<v4f *>(a.G + (blk * 64 + lane) * 4) = g4;
+            const size_t blk = (size_t)(t >> 1) * (a.Bpad >> 6) + (j >> 1);
+            const int nl64 = 32 * (t & 1) + 16 * nbk + c, bl64 = 32 * (j & 1) + 16 * half + 4 * s;
+            *reinterpret_cast<v4f *>(a.G + blk * 4096 + nl64 * 64 + bl64) = g4;
         }
         TL_STAMP();   // [2] start of dC product
         // ---- dC += G^T . Q over this wave's 16 batch rows: A operand straight from g4 ----------------------------
         if (!(a.ablate & 8)) {
             // slot s, step t  <->  batch row 16*half + 4s + t ; A = G[row][n = 16nbk + c] = g4[t], B = Q[row][columns]
-            const float *qb = Qs + (16 * half + 4 * s) * LDK;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float av = g4[t];
-                const float *brow = qb + t * LDK;
+                v4f nb[KQ > 0 ? KQ : 1];
+                float nr[KR > 0 ? KR : 1];
+                if (t + 1 < 4) {
+                    const float *brow = qb + (t + 1) * LDK;
 #pragma unroll
-                for (int kq = 0; kq < KQ; ++kq) {
-                    const v4f b4 = *reinterpret_cast<const v4f *>(brow + 64 * kq + 4 * c);
-                    dc[4 * kq + 0] = mfma16(av, b4[0], dc[4 * kq + 0]);
-                    dc[4 * kq + 1] = mfma16(av, b4[1], dc[4 * kq + 1]);
-                    dc[4 * kq + 2] = mfma16(av, b4[2], dc[4 * kq + 2]);
-                    dc[4 * kq + 3] = mfma16(av, b4[3], dc[4 * kq + 3]);
+                    for (int kq = 0; kq < KQ; ++kq) nb[kq] = *reinterpret_cast<const v4f *>(brow + 64 * kq + 4 * c);
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) nr[r] = brow[64 * KQ + 16 * r + c];
                 }
 #pragma unroll
-                for (int r = 0; r < KR; ++r)
-                    dc[4 * KQ + r] = mfma16(av, brow[64 * KQ + 16 * r + c], dc[4 * KQ + r]);
+                for (int kq = 0; kq < KQ; ++kq) {
+                    dc[4 * kq + 0] = mfma16(av, pb[kq][0], dc[4 * kq + 0]);
+                    dc[4 * kq + 1] = mfma16(av, pb[kq][1], dc[4 * kq + 1]);
+                    dc[4 * kq + 2] = mfma16(av, pb[kq][2], dc[4 * kq + 2]);
+                    dc[4 * kq + 3] = mfma16(av, pb[kq][3], dc[4 * kq + 3]);
+                }
+#pragma unroll
+                for (int r = 0; r < KR; ++r) dc[4 * KQ + r] = mfma16(av, pr[r], dc[4 * KQ + r]);
+                if (t + 1 < 4) {
+#pragma unroll
+                    for (int kq = 0; kq < KQ; ++kq) pb[kq] = nb[kq];
+#pragma unroll
+                    for (int r = 0; r < KR; ++r) pr[r] = nr[r];
+                    __builtin_amdgcn_sched_group_barrier(0x100, KQ + KR, 1);   // next step's ds_reads first
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, KB, 1);            // then this step's MFMAs
             }
         }
         TL_STAMP();   // [3] end of dC product
