@@ -76,6 +76,12 @@ typedef struct okge_candidates {
     int32_t        first_id;
     int32_t        n;
     okge_dropout   drop;
+    /* Optional: gather candidate rows from this (table_rows, d) fp32 table instead of okge_tables.E -- the
+     * reference's _score(subj, rel, obj, prefix=True) receives already-encoded candidate rows
+     * (model.py:181-229).  Scoring only; the training entry point requires table == NULL. */
+    const float   *table;
+    int32_t        table_rows;
+    int32_t        _pad;
 } okge_candidates;
 
 /* Embedding tables: entity_embedding.weight (n_ent, d), relation_embedding.weight (n_rel, d)
@@ -123,6 +129,9 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
  *               zero_grad, trainer.py:229-232); candidate rows are then stored instead of read-modify-written
  * No (B,N) label or score tensor is read; positives come as coordinates. */
 #define OKGE_TRAIN_GRADS_ZERO 1
+/*               OKGE_TRAIN_LOSS_ONLY  -- forward + loss only (validation loss under torch.no_grad(),
+ *               trainer.py:363-369): dE/dR are not touched and may be NULL */
+#define OKGE_TRAIN_LOSS_ONLY 2
 int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch,
                                 const okge_candidates *cand, const okge_positives *pos,
                                 int32_t loss_kind, float label_smoothing, double normalizer, int32_t flags,
@@ -133,6 +142,17 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
 /* Bytes of scratch okge_train_forward_backward / okge_score_prefixes need for a batch of B rows
  * against N candidates with slot size d (0 on invalid arguments). */
 size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d);
+
+/* ---- embedder --------------------------------------------------------------------------------------
+ * Replaces LookupBaseRelationEmbedder._encode for the lookup embedder with batch-norm / projection /
+ * normalisation off (model.py:455-480): out[i][:] = dropout(table[ids ? ids[i] : first_id + i][:]).
+ * Used by the API-compatible encode_subj/rel/obj, get_all_* and precompute_batch_shared_inputs. */
+int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const int32_t *ids, int32_t first_id,
+                     int32_t n, const okge_dropout *drop, float *out, int64_t ld_out, void *stream);
+
+/* x[i] *= *alpha_dev for i < n (alpha is a DEVICE fp32 scalar: the upstream gradient autograd hands to the
+ * fused loss node, i.e. 1/normalizer of trainer.py:221, without a host synchronisation). */
+int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream);
 
 /* ---- dense Adagrad ----------------------------------------------------------------------------------
  * Replaces torch.optim.Adagrad.step as configured by OptimRegime (utils/optim.py:29,139-160):

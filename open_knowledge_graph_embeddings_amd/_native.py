@@ -20,12 +20,13 @@ HEADERS = ["okge_device.h", "okge_kernels.h", os.path.join("..", "..", "include"
 OKGE_COMPLEX, OKGE_DISTMULT = 0, 1
 OKGE_LOSS_BCE, OKGE_LOSS_KL = 0, 1
 OKGE_TRAIN_GRADS_ZERO = 1
+OKGE_TRAIN_LOSS_ONLY = 2
 SCORERS = {"complex": OKGE_COMPLEX, "distmult": OKGE_DISTMULT}
 LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 
 # every symbol include/okge.h declares
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
-           "okge_train_workspace_bytes", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_train_workspace_bytes", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -45,7 +46,8 @@ class PrefixBatch(Structure):
 
 
 class Candidates(Structure):
-    _fields_ = [("ids", c_void_p), ("first_id", c_int32), ("n", c_int32), ("drop", Dropout)]
+    _fields_ = [("ids", c_void_p), ("first_id", c_int32), ("n", c_int32), ("drop", Dropout), ("table", c_void_p),
+                ("table_rows", c_int32), ("_pad", c_int32)]
 
 
 class Tables(Structure):
@@ -98,6 +100,11 @@ def lib():
     L.okge_train_forward_backward.argtypes = [POINTER(Tables), POINTER(PrefixBatch), POINTER(Candidates),
                                               POINTER(Positives), c_int32, c_float, c_double, c_int32, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]
+    L.okge_encode_rows.restype = c_int32
+    L.okge_encode_rows.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, POINTER(Dropout), c_void_p,
+                                   c_int64, c_void_p]
+    L.okge_scale_inplace.restype = c_int32
+    L.okge_scale_inplace.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.okge_adagrad_step.restype = c_int32
     L.okge_adagrad_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int32, c_void_p]
     L.okge_adagrad_step2.restype = c_int32

@@ -181,15 +181,16 @@ int check_common(const okge_tables *t, const okge_prefix_batch *b, const okge_ca
     if (b->n_po > 0 && (!b->po_rel || !b->po_obj)) return fail(OKGE_ERR_INVALID, "null po ids");
     if (b->n_sp > 0 && (!b->sp_subj || !b->sp_rel)) return fail(OKGE_ERR_INVALID, "null sp ids");
     if (c->n <= 0) return fail(OKGE_ERR_INVALID, "no candidates");
-    if (!c->ids && (c->first_id < 0 || (int64_t)c->first_id + c->n > t->n_ent))
-        return fail(OKGE_ERR_INVALID, "candidate range outside the entity table");
+    const int64_t cand_rows = c->table ? c->table_rows : t->n_ent;
+    if (!c->ids && (c->first_id < 0 || (int64_t)c->first_id + c->n > cand_rows))
+        return fail(OKGE_ERR_INVALID, "candidate range outside the candidate table");
     return OKGE_OK;
 }
 
 void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, const okge_candidates *c, char *ws)
 {
     std::memset(&a, 0, sizeof(a));
-    a.E = t->E;
+    a.E = c->table ? c->table : t->E;       // table the candidate rows are gathered from
     a.cand_ids = c->ids;
     a.cand_first = c->first_id;
     a.Q = reinterpret_cast<const float *>(ws + g.off_Q);
@@ -255,7 +256,9 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     if (!pos || pos->nnz < 0 || (pos->nnz > 0 && (!pos->col || !pos->row)))
         return fail(OKGE_ERR_INVALID, "bad positives");
     if (loss_kind != OKGE_LOSS_BCE && loss_kind != OKGE_LOSS_KL) return fail(OKGE_ERR_INVALID, "unknown loss");
-    if (!loss_out || !dE || !dR) return fail(OKGE_ERR_INVALID, "null output");
+    const bool loss_only = (flags & OKGE_TRAIN_LOSS_ONLY) != 0;
+    if (!loss_out || (!loss_only && (!dE || !dR))) return fail(OKGE_ERR_INVALID, "null output");
+    if (cand->table) return fail(OKGE_ERR_INVALID, "training needs candidates from the entity table");
     if (!(normalizer > 0)) return fail(OKGE_ERR_INVALID, "normalizer must be positive");
     if (scores && ld_scores < cand->n) return fail(OKGE_ERR_INVALID, "bad scores buffer");
     Geometry g;
@@ -277,6 +280,7 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     a.pos_col = pos->col; a.pos_row = pos->row; a.nnz = pos->nnz;
     a.tile_ptr = reinterpret_cast<const int32_t *>(ws + g.off_tptr);
     a.grads_zero = (flags & OKGE_TRAIN_GRADS_ZERO) ? 1 : 0;
+    a.loss_only = loss_only ? 1 : 0;
     a.stagger = env_int("OKGE_STAGGER", 0);
     a.ablate = env_int("OKGE_ABLATE", 0);
     a.G = reinterpret_cast<float *>(ws + g.off_GT);
@@ -326,6 +330,12 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
         e = launch_fused32(mode, a, g.ktiles, g.b_split, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
     }
+    if (loss_only) {
+        ScopedTimer tm("loss_reduce", st);
+        e = launch_loss_reduce(a.loss_partial, g.ktiles * g.b_split, loss_out, st);
+        if (e != hipSuccess) return fail_hip(e, "loss_reduce");
+        return OKGE_OK;
+    }
     DqArgs q;
     std::memset(&q, 0, sizeof(q));
     q.G = a.G; q.Cm = a.Cm;
@@ -343,6 +353,32 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
                                    a.loss_partial, g.ktiles * g.b_split, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
     }
+    return OKGE_OK;
+}
+
+int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const int32_t *ids, int32_t first_id, int32_t n,
+                     const okge_dropout *drop, float *out, int64_t ld_out, void *stream)
+{
+    if (!table || !out || d <= 0 || n < 0 || ld_out < d || table_rows <= 0)
+        return fail(OKGE_ERR_INVALID, "bad encode_rows arguments");
+    if (!ids && (first_id < 0 || (int64_t)first_id + n > table_rows))
+        return fail(OKGE_ERR_INVALID, "row range outside the table");
+    okge_dropout none;
+    std::memset(&none, 0, sizeof(none));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("encode_rows", st);
+    hipError_t e = launch_encode_rows(table, d, ids, first_id, n, to_dev(drop ? *drop : none), out, ld_out, st);
+    if (e != hipSuccess) return fail_hip(e, "encode_rows");
+    return OKGE_OK;
+}
+
+int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream)
+{
+    if (!x || !alpha_dev || n < 0) return fail(OKGE_ERR_INVALID, "bad scale arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("scale", st);
+    hipError_t e = launch_scale(x, n, alpha_dev, st);
+    if (e != hipSuccess) return fail_hip(e, "scale");
     return OKGE_OK;
 }
 

@@ -35,6 +35,7 @@ struct FusedArgs {
     int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero;
     float          y_pos, y_neg, inv_norm;
     int32_t        stagger;    // s_sleep units (64 clk) the second-resident workgroups wait before starting
+    int32_t        loss_only;  // forward + loss only: no G store, no dC product, no write-back
     int32_t        ablate;     // diagnostic (OKGE_ABLATE): bit0 no score product, 1 no loss math, 2 no G store,
                                // 3 no dC product, 4 no candidate dropout/Cm store, 5 no dE write-back, 6 no Q staging
 };
@@ -65,8 +66,12 @@ hipError_t launch_encode_queries(const float *E, const float *R, int d, int scor
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
                                   const float *slab, int nsplit, int Bpad, int ldq, float *dE, float *dR,
                                   const double *loss_partials, int n_partials, double *loss_out, hipStream_t st);
+hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
 hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, const int32_t *pos_row, int nnz,
                                float *row_lse, float *row_ysum, hipStream_t st);
+hipError_t launch_encode_rows(const float *table, int d, const int32_t *ids, int first_id, int n, const DropDev &drop,
+                              float *out, int64_t ld_out, hipStream_t st);
+hipError_t launch_scale(float *x, int64_t n, const float *alpha_dev, hipStream_t st);
 hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, float wd, float eps, int zero_grad,
                           hipStream_t st);
 hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p1, float *g1, float *s1, int64_t n1,

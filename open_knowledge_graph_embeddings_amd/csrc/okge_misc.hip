@@ -304,6 +304,24 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, flo
     }
 }
 
+__global__ __launch_bounds__(128) void encode_rows_kernel(const float *__restrict__ table, int d,
+                                                          const int32_t *__restrict__ ids, int first_id, const DropDev drop,
+                                                          float *__restrict__ out, int64_t ld_out)
+{
+    const int i = blockIdx.x;
+    const int64_t row = ids ? (int64_t)ids[i] : (int64_t)first_id + i;
+    const float *src = table + row * d;
+    float *dst = out + (size_t)i * ld_out;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) dst[k] = src[k] * drop_mult1(drop, (uint32_t)i, k, d);
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ x, int64_t n, const float *__restrict__ alpha)
+{
+    const float a = *alpha;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= a;
+}
+
 struct AdagradSeg { float *p, *g, *s; int64_t n; };
 
 __device__ __forceinline__ void adagrad_sweep(const AdagradSeg sg, float lr, float wd, float eps, int zero_grad,
@@ -430,6 +448,12 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
     return hipGetLastError();
 }
 
+hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st)
+{
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, partials, n, loss_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, const int32_t *pos_row, int nnz,
                                float *row_lse, float *row_ysum, hipStream_t st)
 {
@@ -447,6 +471,22 @@ hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, f
     const int64_t n4 = (n + 3) / 4;
     const int blocks = (int)min((int64_t)16384, (n4 + 255) / 256);
     hipLaunchKernelGGL(adagrad_kernel, dim3(blocks), dim3(256), 0, st, p, g, sum, n, lr, wd, eps, zero_grad);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_rows(const float *table, int d, const int32_t *ids, int first_id, int n, const DropDev &drop,
+                              float *out, int64_t ld_out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encode_rows_kernel, dim3(n), dim3(128), 0, st, table, d, ids, first_id, drop, out, ld_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_scale(float *x, int64_t n, const float *alpha_dev, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int)std::min((int64_t)4096, (n + 255) / 256);
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, st, x, n, alpha_dev);
     return hipGetLastError();
 }
 

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         int64_t cid = 0;
         if (valid) cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
         const float *row = a.E + cid * d;
-        float *cm = (blockIdx.y == 0) ? a.Cm + (size_t)n * (16 * KB) : nullptr;
+        float *cm = (blockIdx.y == 0 && !a.loss_only) ? a.Cm + (size_t)n * (16 * KB) : nullptr;
         v4f v0[NOIT], v1[NOIT];
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
             }
         }
         // ---- G block -> HBM for dq_kernel: Gt[T][J][n_local][b_local], 4 consecutive batch rows per lane ----------
-        if (!(a.ablate & 4)) {
+        if (!(a.ablate & 4) && !a.loss_only) {
             const int t = blockIdx.x, j = b0 >> 5;
             const size_t blk = (size_t)(t >> 1) * (a.Bpad >> 6) + (j >> 1);
             const int nl64 = 32 * (t & 1) + 16 * nbk + c, bl64 = 32 * (j & 1) + 16 * half + 4 * s;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         }
         TL_STAMP();   // [2] start of dC product
         // ---- dC += G^T . Q over this wave's 16 batch rows: A operand straight from g4 ----------------------------
-        if (!(a.ablate & 8)) {
+        if (!(a.ablate & 8) && !a.loss_only) {
             // slot s, step t  <->  batch row 16*half + 4s + t ; A = G[row][n = 16nbk + c] = g4[t], B = Q[row][columns]
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
     }
     __syncthreads();
     if (tid == 0) a.loss_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-    if (!(a.ablate & 32)) {
+    if (!(a.ablate & 32) && !a.loss_only) {
         const int n = n0 + r8;
         if (n < a.N) {
             const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;

@@ -57,6 +57,7 @@ class PrefixBatch:
     cand_ids: Optional[torch.Tensor] = None  # int32 [N] or None for the range cand_first .. cand_first+N-1
     cand_first: int = 2
     n_cand: int = 0
+    cand_table: Optional[torch.Tensor] = None  # scoring only: gather candidates from this (rows, d) table, not E
     drop_po_ent: DropoutSpec = field(default_factory=DropoutSpec)
     drop_po_rel: DropoutSpec = field(default_factory=DropoutSpec)
     drop_sp_ent: DropoutSpec = field(default_factory=DropoutSpec)
@@ -142,6 +143,12 @@ class HotPath:
         c.first_id = int(b.cand_first)
         c.n = int(b.n_cand if keep[4] is None else keep[4].numel())
         c.drop = b.drop_cand.c()
+        if b.cand_table is not None:
+            ct = b.cand_table
+            if ct.dtype != torch.float32 or not ct.is_contiguous() or ct.device != dev:
+                raise N.OkgeError("candidate table must be a contiguous fp32 tensor on the engine's device")
+            c.table, c.table_rows = ct.data_ptr(), ct.shape[0]
+            keep.append(ct)
         return pb, c, keep
 
     # -- entry points -------------------------------------------------------------------------------
@@ -161,7 +168,7 @@ class HotPath:
         return out
 
     def forward_backward(self, E, R, scorer, batch: PrefixBatch, dE, dR, loss="bce", label_smoothing=0.0,
-                         normalizer=None, loss_out=None, scores=None, grads_zero=False):
+                         normalizer=None, loss_out=None, scores=None, grads_zero=False, loss_only=False):
         """Fused forward + loss + backward; accumulates into dE / dR; returns the summed loss as a
         device double[1] tensor (no host sync)."""
         pb, c, keep = self._batch(batch)
@@ -178,12 +185,31 @@ class HotPath:
         N.check(self.lib.okge_train_forward_backward(
             ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), ctypes.byref(pos),
             N.LOSSES[loss] if isinstance(loss, str) else int(loss), float(label_smoothing), float(normalizer),
-            N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0,
-            loss_out.data_ptr(), dE.data_ptr(), dR.data_ptr(),
+            (N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0) | (N.OKGE_TRAIN_LOSS_ONLY if loss_only else 0),
+            loss_out.data_ptr(), _ptr(dE), _ptr(dR),
             None if scores is None else scores.data_ptr(), 0 if scores is None else scores.stride(0),
             ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_forward_backward")
         del keep, prow, pcol
         return loss_out
+
+    def encode_rows(self, table, ids=None, first_id=0, n=None, drop: DropoutSpec = NO_DROP, out=None):
+        """dropout(table[ids]) -> (n, d): LookupBaseRelationEmbedder._encode (model.py:455-480)."""
+        ids = _i32(ids, self.device)
+        n = int(ids.numel()) if ids is not None else int(n)
+        d = table.shape[1]
+        if out is None:
+            out = torch.empty((n, d), dtype=torch.float32, device=self.device)
+        dc = drop.c()
+        N.check(self.lib.okge_encode_rows(table.data_ptr(), table.shape[0], d, _ptr(ids), int(first_id), n,
+                                          ctypes.byref(dc), out.data_ptr(), out.stride(0), self._stream()),
+                "okge_encode_rows")
+        return out
+
+    def scale_(self, x, alpha_dev):
+        """x *= alpha (device fp32 scalar) in place."""
+        N.check(self.lib.okge_scale_inplace(x.data_ptr(), x.numel(), alpha_dev.data_ptr(), self._stream()),
+                "okge_scale_inplace")
+        return x
 
     def adagrad(self, p, g, state_sum, lr, weight_decay=1e-10, eps=1e-8, zero_grad=True):
         N.check(self.lib.okge_adagrad_step(p.data_ptr(), g.data_ptr(), state_sum.data_ptr(), p.numel(), float(lr),

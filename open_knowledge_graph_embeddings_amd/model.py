@@ -1,0 +1,243 @@
+"""Plugin surface of the hot path: the reference's RelationScorer x RelationEmbedder composition and the
+``Models`` registry (openkge/model.py:31-139, :176-278, :353-558, :1006-1066), backed by the HIP kernels.
+
+Same class names, constructor keywords, method names and tensor conventions as the reference:
+ids are int32 ``(b, 1)`` (or ``(N,)`` for candidates), scores come back ``(b, N)`` fp32, state-dict keys are
+``entity_embedding.weight`` and ``relation_embedding.weight``.  What differs:
+
+* every arithmetic step runs in libokge_hip.so (no ATen math); the methods return plain tensors without an
+  autograd graph.  Gradients are produced by ``trainer.AddLossModule`` (fused forward + loss + backward), which
+  is how the reference's Trainer consumes the model (openkge/trainer.py:142,206-234);
+* only the configuration the fused path covers is accepted: lookup embedder with batch_norm / projection /
+  normalize / l2_reg off and dense gradients.  Anything else raises NotImplementedError at construction;
+* the two dropouts the reference applies in sequence (input_dropout, dropout; model.py:461-470) draw from a
+  counter-based Philox stream instead of torch's global generator.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hotpath as H
+from ._native import OkgeError
+
+PAD = 0   # openkge/index_mapper.py:14  (ids 0, 1 are reserved; real ids start at 2)
+
+
+class RelationModel(torch.nn.Module):
+    """openkge/model.py:14-28"""
+    is_cuda = False
+
+    def cuda(self, device=None):
+        super().cuda(device=device)
+        self.is_cuda = True
+        return self
+
+    def cpu(self):
+        raise OkgeError("this model runs on an MI355X; there is no CPU path")
+
+
+class RelationScorer(RelationModel):
+    """openkge/model.py:31-77"""
+    scorer_name = None
+
+    def forward(self, subj, rel, obj, **kwargs):
+        return self.triple_score(self.encode_subj(subj), self.encode_rel(rel), self.encode_obj(obj), **kwargs)
+
+    def triple_score(self, subj, rel, obj, **kwargs):
+        # model.py:178-179, :231-238 / :245-246, :276 -- the per-triple Hadamard form is not on the prefix-scoring
+        # path (trainer.py:64 returns None for input_style 'triple'); not provided.
+        raise NotImplementedError("triple scoring is outside the fused prefix-scoring path")
+
+    def sp_prefix_score(self, subj=None, rel=None, many_obj=None):
+        """scores (b, N) of (subj, rel, ?) against all objects, or against pre-encoded rows `many_obj`."""
+        return self._prefix_score(H.PrefixBatch(sp_subj=subj, sp_rel=rel), many_obj)
+
+    def po_prefix_score(self, rel=None, obj=None, many_subj=None):
+        """scores (b, N) of (?, rel, obj) against all subjects, or against pre-encoded rows `many_subj`."""
+        return self._prefix_score(H.PrefixBatch(po_rel=rel, po_obj=obj), many_subj)
+
+    def precompute_batch_shared_inputs(self, entity_ids):
+        return self.encode_obj(entity_ids)
+
+    def _score(self, subj, rel, obj, prefix=False, sp=None, po=None):
+        """openkge/model.py:181-240 / :248-278 on ALREADY ENCODED rows: (b,d),(b,d),(N,d) -> (b,N)."""
+        if not prefix:
+            return self.triple_score(subj, rel, obj)
+        eng = self.engine()
+        rel = rel.reshape(-1, rel.shape[-1]).contiguous()
+        b = rel.shape[0]
+        ar = torch.arange(b, dtype=torch.int32, device=rel.device)
+        if sp:
+            ent, cand = subj.reshape(-1, subj.shape[-1]).contiguous(), obj.reshape(-1, obj.shape[-1]).contiguous()
+            batch = H.PrefixBatch(sp_subj=ar, sp_rel=ar)
+        elif po:
+            ent, cand = obj.reshape(-1, obj.shape[-1]).contiguous(), subj.reshape(-1, subj.shape[-1]).contiguous()
+            batch = H.PrefixBatch(po_rel=ar, po_obj=ar)
+        else:
+            raise Exception      # model.py:217-218, :273-274
+        batch.cand_table, batch.cand_first, batch.n_cand = cand, 0, cand.shape[0]
+        return eng.score(ent, rel, self.scorer_name, batch)
+
+
+class ComplexRelationScorer(RelationScorer):
+    scorer_name = "complex"
+
+
+class DistmultRelationScorer(RelationScorer):
+    scorer_name = "distmult"
+
+
+class RelationEmbedder(RelationModel):
+    """openkge/model.py:80-139 (abstract protocol)"""
+
+    def precompute_embeddings_from_tokens(self):
+        raise NotImplementedError
+
+
+class LookupBaseRelationEmbedder(RelationEmbedder):
+    """openkge/model.py:353-542, restricted to what the fused path implements."""
+
+    def __init__(self, entity_slot_size, relation_slot_size, train_data, entity_embedding_size=None,
+                 relation_embedding_size=None, normalize='', dropout=0.0, input_dropout=0.0, relation_dropout=0.0,
+                 relation_input_dropout=0.0, project_entity=False, project_entity_activation='ReLU',
+                 project_relation=True, project_relation_activation=None, sparse=False, init_std=0.01,
+                 batch_norm=False, l2_reg=0, seed=0):
+        super().__init__()
+        unsupported = dict(normalize=normalize, project_entity=project_entity, project_relation=project_relation,
+                           sparse=sparse, batch_norm=batch_norm, l2_reg=l2_reg)
+        bad = {k: v for k, v in unsupported.items() if v}
+        if bad or (entity_embedding_size not in (None, entity_slot_size)) or \
+                (relation_embedding_size not in (None, entity_slot_size)):
+            raise NotImplementedError(f"outside the fused lookup path (openkge/model.py:463-479 variants): {bad}")
+        self.train_data = train_data
+        self.slot_size = entity_slot_size
+        self.entity_embedding = torch.nn.Embedding(train_data.entities_size, entity_slot_size, padding_idx=PAD)
+        self.relation_embedding = torch.nn.Embedding(train_data.relations_size, entity_slot_size, padding_idx=PAD)
+        torch.nn.init.normal_(self.entity_embedding.weight.data, std=init_std)       # model.py:429-430
+        torch.nn.init.normal_(self.relation_embedding.weight.data, std=init_std)
+        self.dropout = dropout
+        self.input_dropout = input_dropout
+        self.relation_dropout = dropout if relation_dropout is None else relation_dropout          # model.py:434-435
+        self.relation_input_dropout = input_dropout if relation_input_dropout is None else relation_input_dropout
+        self.project_entity = self.project_relation = self.batch_norm = False
+        self.normalize, self.l2_reg = '', 0
+        self.dropout_seed = seed
+        self.dropout_step = 0          # advanced once per training batch by AddLossModule
+        self._engine = None
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def engine(self) -> H.HotPath:
+        dev = self.entity_embedding.weight.device
+        if self._engine is None or self._engine.device != dev:
+            self._engine = H.HotPath(dev)
+        return self._engine
+
+    @property
+    def E(self):
+        return self.entity_embedding.weight.data
+
+    @property
+    def R(self):
+        return self.relation_embedding.weight.data
+
+    def keep_prob_dropout(self, p_in, p_out):
+        """Two dropouts in sequence (model.py:461-462, :469-470) == one with keep prob (1-p_in)(1-p_out)."""
+        if not self.training:
+            return 0.0
+        return 1.0 - (1.0 - p_in) * (1.0 - p_out)
+
+    def dropout_spec(self, stream, relation=False):
+        p = self.keep_prob_dropout(self.relation_input_dropout, self.relation_dropout) if relation else \
+            self.keep_prob_dropout(self.input_dropout, self.dropout)
+        return H.DropoutSpec(p, self.dropout_seed, stream, self.dropout_step)
+
+    def after_batch_loss_hook(self, epoch):
+        return None                       # l2_reg hook (model.py:447-453) is off on this path
+
+    # -- RelationEmbedder protocol ------------------------------------------------------------------
+    def _encode(self, table, slot_item, stream, relation, lookup=True):
+        eng = self.engine()
+        if not lookup:                    # model.py:459-460: already rows, only dropout applies
+            rows = slot_item.contiguous()
+            return eng.encode_rows(rows, None, 0, rows.shape[0], self.dropout_spec(stream, relation))
+        return eng.encode_rows(table, slot_item.reshape(-1), drop=self.dropout_spec(stream, relation))
+
+    def encode_subj(self, subj, lookup=True):
+        return self._encode(self.E, subj, H.STREAM_SP_ENT, False, lookup)
+
+    def encode_obj(self, obj, lookup=True):
+        return self._encode(self.E, obj, H.STREAM_PO_ENT, False, lookup)
+
+    def encode_rel(self, rel, lookup=True):
+        return self._encode(self.R, rel, H.STREAM_SP_REL, True, lookup)
+
+    def _get_all(self, table, min_size, stream, relation):
+        return self.engine().encode_rows(table, None, min_size, table.shape[0] - min_size,
+                                         self.dropout_spec(stream, relation))
+
+    def get_all_subj(self):
+        return self._get_all(self.E, self.train_data.min_entities_size, H.STREAM_CAND, False)
+
+    def get_all_obj(self):
+        return self._get_all(self.E, self.train_data.min_entities_size, H.STREAM_CAND, False)
+
+    def get_all_rel(self):
+        return self._get_all(self.R, self.train_data.min_relations_size, H.STREAM_SP_REL, True)
+
+    def _get(self, encode, id):
+        return encode(torch.tensor([id], dtype=torch.int32, device=self.E.device))
+
+    def get_subj(self, subj):
+        return self._get(self.encode_subj, subj)
+
+    def get_rel(self, rel):
+        return self._get(self.encode_rel, rel)
+
+    def get_obj(self, obj):
+        return self._get(self.encode_obj, obj)
+
+    def get_slot_size(self):
+        return self.slot_size
+
+    # -- fused prefix scoring (ids in, scores out) -----------------------------------------------------
+    def _prefix_score(self, batch: H.PrefixBatch, many=None):
+        eng = self.engine()
+        if many is None:                   # all entities with id >= min_entities_size (model.py:512-523)
+            batch.cand_first = self.train_data.min_entities_size
+            batch.n_cand = self.E.shape[0] - batch.cand_first
+            batch.drop_cand = self.dropout_spec(H.STREAM_CAND)
+        else:                              # rows already encoded by precompute_batch_shared_inputs / get_all_obj
+            many = many.reshape(-1, many.shape[-1]).contiguous()
+            batch.cand_table, batch.cand_first, batch.n_cand = many, 0, many.shape[0]
+        batch.drop_po_ent, batch.drop_sp_ent = self.dropout_spec(H.STREAM_PO_ENT), self.dropout_spec(H.STREAM_SP_ENT)
+        batch.drop_po_rel = self.dropout_spec(H.STREAM_PO_REL, True)
+        batch.drop_sp_rel = self.dropout_spec(H.STREAM_SP_REL, True)
+        return eng.score(self.E, self.R, self.scorer_name, batch)
+
+
+class LookupSimpleRelationEmbedder(LookupBaseRelationEmbedder):
+    """openkge/model.py:545-558: relation slot = entity slot, no relation projection."""
+
+    def __init__(self, entity_slot_size, **kwargs):
+        kwargs.pop('relation_slot_size', None)
+        kwargs.pop('project_relation', None)
+        super().__init__(entity_slot_size=entity_slot_size, relation_slot_size=entity_slot_size,
+                         project_relation=False, **kwargs)
+        self.relation_projection = None
+
+
+class LookupComplexRelationModel(ComplexRelationScorer, LookupSimpleRelationEmbedder):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+
+class LookupDistmultRelationModel(DistmultRelationScorer, LookupSimpleRelationEmbedder):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+
+class Models:
+    """openkge/model.py:1052-1066: looked up with getattr(Models, args['model']) (scripts/train.py:88).
+    Only the two models of the fused path are registered; the others stay with the reference."""
+    LookupDistmultRelationModel = LookupDistmultRelationModel
+    LookupComplexRelationModel = LookupComplexRelationModel

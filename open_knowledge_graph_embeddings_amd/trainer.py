@@ -1,0 +1,141 @@
+"""Trainer-side surface of the hot path (openkge/trainer.py:32-113, :181-272; openkge/dataset.py:423-453).
+
+``AddLossModule`` keeps the reference's constructor and ``forward`` signature and return triple
+``(loss, hook_loss, all_outputs)``.  In training mode one fused HIP call computes the loss AND the gradients;
+the returned loss is wired into autograd by a custom Function so the reference Trainer's
+``(loss.sum() / normalizer).backward()`` (trainer.py:217-234) deposits them in ``weight.grad`` unchanged.
+``compute_metrics`` mirrors OneToNMentionRelationDataset.compute_metrics on the HIP rank kernel.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.nn import BCEWithLogitsLoss, KLDivLoss
+
+from . import hotpath as H
+from .metrics import MetricResult
+
+
+class _FusedLossFn(torch.autograd.Function):
+    """Autograd node standing for AddLossModule's whole forward: the gradients of the SUMMED loss were already
+    produced by the fused kernel; backward scales them by the upstream scalar (1/normalizer) on the device."""
+
+    @staticmethod
+    def forward(ctx, e_weight, r_weight, loss, g_e, g_r, engine):
+        ctx.g_e, ctx.g_r, ctx.engine = g_e, g_r, engine
+        return loss.to(torch.float32).reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        alpha = grad_out.reshape(1).to(torch.float32).contiguous()
+        ctx.engine.scale_(ctx.g_e, alpha)
+        ctx.engine.scale_(ctx.g_r, alpha)
+        return ctx.g_e, ctx.g_r, None, None, None, None
+
+
+def _flat(t):
+    return None if t is None else t.reshape(-1)
+
+
+class AddLossModule(nn.Module):
+    """openkge/trainer.py:32-113."""
+
+    def __init__(self, model, loss, bce_label_smoothing=0.0):
+        super().__init__()
+        self.model = model
+        self.loss = loss
+        self.bce_label_smoothing = bce_label_smoothing
+
+    def _loss_kind(self):
+        if isinstance(self.loss, KLDivLoss):
+            return "kl"
+        if isinstance(self.loss, BCEWithLogitsLoss):
+            return "bce"
+        raise NotImplementedError(f"{self.loss} not supported. Please choose either BCEWithLogitsLoss or KLDivLoss")
+
+    def forward(self, inputs, labels, use_batch_shared_entities, batch_shared_entities, epoch=-1,
+                input_style_triple_or_prefix="triple"):
+        allowed = ["triple", "right_and_left_prefix"]
+        if input_style_triple_or_prefix not in allowed:
+            raise Exception("input_style_triple_or_prefix not in {}".format(allowed))
+        if input_style_triple_or_prefix != "right_and_left_prefix":
+            return None                                            # trainer.py:64 has no else branch
+        kind = self._loss_kind()
+        m = self.model
+        eng = m.engine()
+        po, sp = inputs
+        batch = H.PrefixBatch()
+        if po is not None:
+            batch.po_rel, batch.po_obj = _flat(po[0]), _flat(po[1])
+        if sp is not None:
+            batch.sp_subj, batch.sp_rel = _flat(sp[0]), _flat(sp[1])
+        # candidates: all entities in eval without batch sharing (trainer.py:77-78), else the shared id list
+        if batch_shared_entities is None or (not use_batch_shared_entities and not m.training):
+            batch.cand_first = m.train_data.min_entities_size
+            batch.n_cand = m.E.shape[0] - batch.cand_first
+        else:
+            ids = batch_shared_entities.reshape(-1)
+            first = m.train_data.min_entities_size
+            if ids.numel() == m.E.shape[0] - first and not use_batch_shared_entities:
+                batch.cand_first, batch.n_cand = first, int(ids.numel())      # arange(vocab)[offset:] (dataset.py:872)
+            else:
+                batch.cand_ids, batch.n_cand = ids, int(ids.numel())
+        if isinstance(labels, tuple):                               # (pos_row, pos_col) coordinates
+            batch.pos_row, batch.pos_col = labels
+        else:                                                       # dense (B, N) {0,1} (dataset.py:885-932)
+            batch.pos_row, batch.pos_col = H.positives_from_dense(labels.to(m.E.device))
+        if m.training:
+            m.dropout_step += 1
+        batch.drop_cand = m.dropout_spec(H.STREAM_CAND)
+        batch.drop_po_ent, batch.drop_sp_ent = m.dropout_spec(H.STREAM_PO_ENT), m.dropout_spec(H.STREAM_SP_ENT)
+        batch.drop_po_rel, batch.drop_sp_rel = m.dropout_spec(H.STREAM_PO_REL, True), m.dropout_spec(H.STREAM_SP_REL, True)
+        B, n = batch.B, batch.n_cand
+        all_outputs = torch.empty((B, (n + 3) // 4 * 4), dtype=torch.float32, device=m.E.device)[:, :n]
+        smoothing = self.bce_label_smoothing if kind == "bce" else 0.0
+        hook_loss = m.after_batch_loss_hook(epoch) if hasattr(m, "after_batch_loss_hook") else None
+        want_grad = torch.is_grad_enabled() and m.training
+        if want_grad:
+            g_e, g_r = torch.zeros_like(m.E), torch.zeros_like(m.R)
+            loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, g_e, g_r, loss=kind, label_smoothing=smoothing,
+                                        normalizer=1.0, scores=all_outputs, grads_zero=True)
+            result = _FusedLossFn.apply(m.entity_embedding.weight, m.relation_embedding.weight, loss, g_e, g_r, eng)
+        else:
+            loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, None, None, loss=kind, label_smoothing=smoothing,
+                                        normalizer=1.0, scores=all_outputs, loss_only=True)
+            result = loss.to(torch.float32).reshape(())
+        return result, hook_loss, all_outputs
+
+
+def compute_metrics(filter_mask, label_ids, predictions, engine: H.HotPath = None) -> MetricResult:
+    """OneToNMentionRelationDataset.compute_metrics (dataset.py:423-453) on the HIP rank kernel.
+
+    filter_mask (B, N) bool; label_ids list[B] of list[G_b] of int tensors (candidate-relative ids);
+    predictions (B, N) fp32 on the GPU.  Returns the same seven meters, weighted by number of groups per row."""
+    dev = predictions.device
+    engine = engine or H.HotPath(dev)
+    row_ptr, grp_ptr, ids = [0], [0], []
+    for groups in label_ids:
+        for g in groups:
+            ids.extend(int(x) for x in g.reshape(-1).tolist())
+            grp_ptr.append(len(ids))
+        row_ptr.append(len(grp_ptr) - 1)
+    fm = filter_mask.to(dev)
+    nz = fm.nonzero()                                            # sorted by row: CSR columns
+    filt_ptr = torch.zeros(fm.shape[0] + 1, dtype=torch.int64, device=dev)
+    filt_ptr[1:] = torch.cumsum(fm.sum(1), 0)
+    filt_col = nz[:, 1].to(torch.int32).contiguous()
+    t = lambda a, dt: torch.tensor(a, dtype=dt, device=dev)        # noqa: E731
+    preds = predictions if predictions.stride(1) == 1 else predictions.contiguous()
+    ranks = engine.filtered_ranks(preds, filt_ptr, filt_col, t(row_ptr, torch.int64), t(grp_ptr, torch.int64),
+                                  t(ids, torch.int32)).cpu()
+    result = MetricResult()
+    for b in range(len(label_ids)):
+        r = ranks[row_ptr[b]:row_ptr[b + 1]]
+        n = int(r.numel())
+        if n == 0:
+            continue
+        result["mrr"].update((1.0 / (r + 1).float()).sum().item() / n, n)
+        result["mr"].update(r.sum().item() / n, n)
+        for k in (50, 10, 3, 1):
+            result[f"h{k}"].update((r < k).float().sum().item() / n, n)
+    return result
