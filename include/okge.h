@@ -139,6 +139,37 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
                                 float *scores, int64_t ld_scores,
                                 void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the same step in three phases, for an entity table row-sharded across devices -------------------------
+ * (the reference has no counterpart: its only multi-device mechanism is nn.DataParallel, trainer.py:143-145.)
+ * Rank r holds entity rows [ent_lo, ent_hi) (okge_tables.E points at its slice, n_ent = ent_hi - ent_lo) plus
+ * the whole relation table.  One step on every rank, with two small all-reduces supplied by the caller (RCCL):
+ *   1. okge_encode_queries  : query rows (and the masked prefix entity rows) of the prefixes whose entity this
+ *                             rank owns, zeros elsewhere            -> all-reduce(sum) of Q and ent_rows
+ *   2. okge_train_tiles     : score/loss/dCand against the LOCAL candidates, dE of the local rows, partial dQ
+ *                                                                   -> all-reduce(sum) of dQ (and of the loss)
+ *   3. okge_prefix_backward : chain rule; entity gradients scattered by the owner, relation gradients formed
+ *                             identically on every rank from ent_rows.
+ * cand_col0 = position of the first local candidate in the un-sharded candidate list: positives keep their
+ * global columns and dropout masks are identical to the single-device run.  BCE only (the KL loss would need
+ * per-row max / sum-exp exchanged between the ranks). */
+typedef struct okge_shard {
+    int32_t ent_lo, ent_hi;
+    int32_t cand_col0;
+    int32_t _pad;
+} okge_shard;
+
+int64_t okge_query_ld(int32_t d);      /* leading dimension (floats) of Q / ent_rows / dQ blocks for slot size d */
+int32_t okge_query_rows(int32_t B);    /* rows those blocks must have (B rounded up to the 64-row chunk)         */
+
+int okge_encode_queries(const okge_tables *t, const okge_shard *shard, const okge_prefix_batch *batch,
+                        float *Q, int64_t ldq, float *ent_rows, void *stream);
+int okge_train_tiles(const okge_tables *t, const okge_shard *shard, const float *Q, int64_t ldq, int32_t B,
+                     const okge_candidates *local_cand, const okge_positives *pos, int32_t loss_kind,
+                     float label_smoothing, double normalizer, int32_t n_cand_global, int32_t flags,
+                     double *loss_out, float *dE, float *dQ, void *workspace, size_t workspace_bytes, void *stream);
+int okge_prefix_backward(const okge_tables *t, const okge_shard *shard, const okge_prefix_batch *batch,
+                         const float *dQ, int64_t ldq, const float *ent_rows, float *dE, float *dR, void *stream);
+
 /* Bytes of scratch okge_train_forward_backward / okge_score_prefixes need for a batch of B rows
  * against N candidates with slot size d (0 on invalid arguments). */
 size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d);

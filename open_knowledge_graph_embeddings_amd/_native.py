@@ -26,7 +26,8 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 
 # every symbol include/okge.h declares
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
-           "okge_train_workspace_bytes", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_train_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
+           "okge_prefix_backward", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -53,6 +54,10 @@ class Candidates(Structure):
 class Tables(Structure):
     _fields_ = [("E", c_void_p), ("R", c_void_p), ("n_ent", c_int32), ("n_rel", c_int32), ("d", c_int32),
                 ("scorer", c_int32)]
+
+
+class Shard(Structure):
+    _fields_ = [("ent_lo", c_int32), ("ent_hi", c_int32), ("cand_col0", c_int32), ("_pad", c_int32)]
 
 
 class Positives(Structure):
@@ -100,6 +105,20 @@ def lib():
     L.okge_train_forward_backward.argtypes = [POINTER(Tables), POINTER(PrefixBatch), POINTER(Candidates),
                                               POINTER(Positives), c_int32, c_float, c_double, c_int32, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]
+    L.okge_query_ld.restype = c_int64
+    L.okge_query_ld.argtypes = [c_int32]
+    L.okge_query_rows.restype = c_int32
+    L.okge_query_rows.argtypes = [c_int32]
+    L.okge_encode_queries.restype = c_int32
+    L.okge_encode_queries.argtypes = [POINTER(Tables), POINTER(Shard), POINTER(PrefixBatch), c_void_p, c_int64, c_void_p,
+                                      c_void_p]
+    L.okge_train_tiles.restype = c_int32
+    L.okge_train_tiles.argtypes = [POINTER(Tables), POINTER(Shard), c_void_p, c_int64, c_int32, POINTER(Candidates),
+                                   POINTER(Positives), c_int32, c_float, c_double, c_int32, c_int32, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]
+    L.okge_prefix_backward.restype = c_int32
+    L.okge_prefix_backward.argtypes = [POINTER(Tables), POINTER(Shard), POINTER(PrefixBatch), c_void_p, c_int64, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]
     L.okge_encode_rows.restype = c_int32
     L.okge_encode_rows.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, POINTER(Dropout), c_void_p,
                                    c_int64, c_void_p]

@@ -97,11 +97,13 @@ DropDev to_dev(const okge_dropout &d)
     return r;
 }
 
-PrefixDev to_dev(const okge_prefix_batch &b)
+PrefixDev to_dev(const okge_prefix_batch &b, const okge_shard *sh = nullptr)
 {
     PrefixDev p;
     p.po_rel = b.po_rel; p.po_obj = b.po_obj; p.sp_subj = b.sp_subj; p.sp_rel = b.sp_rel;
     p.n_po = b.n_po; p.n_sp = b.n_sp;
+    p.ent_lo = sh ? sh->ent_lo : 0;
+    p.ent_hi = sh ? sh->ent_hi : 0x7fffffff;
     p.drop_po_ent = to_dev(b.drop_po_ent); p.drop_po_rel = to_dev(b.drop_po_rel);
     p.drop_sp_ent = to_dev(b.drop_sp_ent); p.drop_sp_rel = to_dev(b.drop_sp_rel);
     return p;
@@ -229,7 +231,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     {
         ScopedTimer tm("encode_queries", st);
         hipError_t e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q),
-                                             g.ldq, g.Bpad, nullptr, 0, nullptr, g.tiles, NT, st);
+                                             g.ldq, g.Bpad, nullptr, nullptr, 0, nullptr, g.tiles, NT, 0, st);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
@@ -246,37 +248,46 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     return OKGE_OK;
 }
 
-int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
-                                const okge_positives *pos, int32_t loss_kind, float label_smoothing,
-                                double normalizer, int32_t flags, double *loss_out, float *dE, float *dR,
-                                float *scores, int64_t ld_scores, void *workspace, size_t workspace_bytes,
-                                void *stream)
+// Shared core of the single-device step and of the sharded okge_train_tiles.
+//   q_ext   : folded queries computed elsewhere (sharded path) or nullptr (encode them here from `batch`)
+//   dq_out  : if set, the dQ slabs are reduced into it and the prefix backward is left to the caller
+static int train_core(const okge_tables *t, const okge_shard *sh, const okge_prefix_batch *batch, const float *q_ext,
+                      int64_t ldq_ext, int32_t B, const okge_candidates *cand, const okge_positives *pos,
+                      int32_t loss_kind, float label_smoothing, double normalizer, int32_t n_cand_global, int32_t flags,
+                      double *loss_out, float *dE, float *dR, float *dq_out, float *scores, int64_t ld_scores,
+                      void *workspace, size_t workspace_bytes, void *stream)
 {
-    if (int rc = check_common(t, batch, cand)) return rc;
     if (!pos || pos->nnz < 0 || (pos->nnz > 0 && (!pos->col || !pos->row)))
         return fail(OKGE_ERR_INVALID, "bad positives");
     if (loss_kind != OKGE_LOSS_BCE && loss_kind != OKGE_LOSS_KL) return fail(OKGE_ERR_INVALID, "unknown loss");
     const bool loss_only = (flags & OKGE_TRAIN_LOSS_ONLY) != 0;
-    if (!loss_out || (!loss_only && (!dE || !dR))) return fail(OKGE_ERR_INVALID, "null output");
+    if (!loss_out || (!loss_only && !dE)) return fail(OKGE_ERR_INVALID, "null output");
     if (cand->table) return fail(OKGE_ERR_INVALID, "training needs candidates from the entity table");
     if (!(normalizer > 0)) return fail(OKGE_ERR_INVALID, "normalizer must be positive");
     if (scores && ld_scores < cand->n) return fail(OKGE_ERR_INVALID, "bad scores buffer");
     Geometry g;
-    make_geometry(batch->n_po + batch->n_sp, cand->n, t->d, g);
+    make_geometry(B, cand->n, t->d, g);
     if (!workspace || workspace_bytes < g.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+    if (q_ext && ldq_ext != g.ldq) return fail(OKGE_ERR_INVALID, "query block leading dimension must be okge_query_ld(d)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
-    const PrefixDev p = to_dev(*batch);
+    const int cand_col0 = sh ? sh->cand_col0 : 0;
     hipError_t e;
     {
+        // folded queries (unless supplied) + per-tile offsets into the column-sorted positives
         ScopedTimer tm("encode_queries", st);
+        PrefixDev p;
+        std::memset(&p, 0, sizeof(p));
+        if (!q_ext) p = to_dev(*batch, sh);
         e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
-                                  g.Bpad, pos->col, pos->nnz, reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles,
-                                  g.tile_w, st);
+                                  q_ext ? 0 : g.Bpad, nullptr, pos->col, pos->nnz,
+                                  reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles, g.tile_w, cand_col0, st);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
     fill_fused_common(a, g, t, cand, ws);
+    if (q_ext) a.Q = q_ext;
+    a.cand_col0 = cand_col0;
     a.pos_col = pos->col; a.pos_row = pos->row; a.nnz = pos->nnz;
     a.tile_ptr = reinterpret_cast<const int32_t *>(ws + g.off_tptr);
     a.grads_zero = (flags & OKGE_TRAIN_GRADS_ZERO) ? 1 : 0;
@@ -289,10 +300,10 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     a.loss_partial = reinterpret_cast<double *>(ws + g.off_loss);
     a.loss_kind = loss_kind;
     a.inv_norm = (float)(1.0 / normalizer);
-    // label smoothing (trainer.py:103-105): y <- (y + 1/N) * (1 - eps), bce branch only
+    // label smoothing (trainer.py:103-105): y <- (y + 1/N) * (1 - eps), bce branch only; N = all candidates
     a.y_pos = 1.f; a.y_neg = 0.f;
     if (loss_kind == OKGE_LOSS_BCE && label_smoothing > 0.f) {
-        const float invn = 1.0f / (float)cand->n;
+        const float invn = 1.0f / (float)(n_cand_global > 0 ? n_cand_global : cand->n);
         a.y_pos = (1.0f + invn) * (1.0f - label_smoothing);
         a.y_neg = (0.0f + invn) * (1.0f - label_smoothing);
     }
@@ -306,6 +317,7 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     if (loss_kind == OKGE_LOSS_KL) {
+        if (sh) return fail(OKGE_ERR_UNSUPPORTED, "the KL loss needs row statistics across shards: not implemented");
         FusedArgs s = a;
         s.stats = reinterpret_cast<float *>(ws + g.off_stats);
         s.b_per_block = g.Bpad;
@@ -347,12 +359,107 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
         e = launch_dq(q, (g.Bpad / BC) * g.nsplit, st);
         if (e != hipSuccess) return fail_hip(e, "dq_kernel");
     }
+    if (dq_out) {
+        {
+            ScopedTimer tm("slab_reduce", st);
+            e = launch_slab_reduce(q.slab, g.nsplit, (int64_t)g.Bpad * g.ldq, dq_out, st);
+            if (e != hipSuccess) return fail_hip(e, "slab_reduce");
+        }
+        ScopedTimer tm("loss_reduce", st);
+        e = launch_loss_reduce(a.loss_partial, g.ktiles * g.b_split, loss_out, st);
+        if (e != hipSuccess) return fail_hip(e, "loss_reduce");
+        return OKGE_OK;
+    }
     {
         ScopedTimer tm("prefix_backward", st);      // + the deterministic loss reduction (one extra workgroup)
-        e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, dE, dR,
+        const PrefixDev p = to_dev(*batch, sh);
+        e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, nullptr, dE, dR,
                                    a.loss_partial, g.ktiles * g.b_split, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
     }
+    return OKGE_OK;
+}
+
+int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                                const okge_positives *pos, int32_t loss_kind, float label_smoothing,
+                                double normalizer, int32_t flags, double *loss_out, float *dE, float *dR,
+                                float *scores, int64_t ld_scores, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    if (int rc = check_common(t, batch, cand)) return rc;
+    if (!(flags & OKGE_TRAIN_LOSS_ONLY) && !dR) return fail(OKGE_ERR_INVALID, "null output");
+    return train_core(t, nullptr, batch, nullptr, 0, batch->n_po + batch->n_sp, cand, pos, loss_kind, label_smoothing,
+                      normalizer, cand->n, flags, loss_out, dE, dR, nullptr, scores, ld_scores, workspace,
+                      workspace_bytes, stream);
+}
+
+// ---- entity-sharded phases ---------------------------------------------------------------------------------------
+int64_t okge_query_ld(int32_t d)
+{
+    Geometry g;
+    return make_geometry(1, 1, d, g) ? g.ldq : 0;
+}
+
+int32_t okge_query_rows(int32_t B) { return B > 0 ? (B + BC - 1) / BC * BC : 0; }
+
+static int check_shard(const okge_tables *t, const okge_shard *sh)
+{
+    if (!sh) return fail(OKGE_ERR_INVALID, "null shard descriptor");
+    if (sh->ent_lo < 0 || sh->ent_hi <= sh->ent_lo || sh->ent_hi - sh->ent_lo != t->n_ent)
+        return fail(OKGE_ERR_INVALID, "shard range must cover exactly the rows of the local entity table");
+    return OKGE_OK;
+}
+
+int okge_encode_queries(const okge_tables *t, const okge_shard *sh, const okge_prefix_batch *batch, float *Q,
+                        int64_t ldq, float *ent_rows, void *stream)
+{
+    okge_candidates none;
+    std::memset(&none, 0, sizeof(none));
+    none.n = 1; none.first_id = 0;
+    if (int rc = check_common(t, batch, &none)) return rc;
+    if (int rc = check_shard(t, sh)) return rc;
+    if (!Q || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad query block");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PrefixDev p = to_dev(*batch, sh);
+    ScopedTimer tm("encode_queries", st);
+    hipError_t e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, Q, (int)ldq,
+                                         okge_query_rows(batch->n_po + batch->n_sp), ent_rows, nullptr, 0, nullptr, 0,
+                                         NT, 0, st);
+    if (e != hipSuccess) return fail_hip(e, "encode_queries");
+    return OKGE_OK;
+}
+
+int okge_train_tiles(const okge_tables *t, const okge_shard *sh, const float *Q, int64_t ldq, int32_t B,
+                     const okge_candidates *cand, const okge_positives *pos, int32_t loss_kind, float label_smoothing,
+                     double normalizer, int32_t n_cand_global, int32_t flags, double *loss_out, float *dE, float *dQ,
+                     void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!t || !cand || !t->E || t->d <= 0 || t->n_ent <= 0) return fail(OKGE_ERR_INVALID, "bad tables");
+    if (t->d > 256) return fail(OKGE_ERR_UNSUPPORTED, "slot size > 256 is not supported by the fused tile kernel yet");
+    if (int rc = check_shard(t, sh)) return rc;
+    if (!Q || !dQ || B <= 0 || cand->n <= 0) return fail(OKGE_ERR_INVALID, "bad query block / candidates");
+    if (!cand->ids && (cand->first_id < 0 || (int64_t)cand->first_id + cand->n > t->n_ent))
+        return fail(OKGE_ERR_INVALID, "candidate range outside the local entity table");
+    return train_core(t, sh, nullptr, Q, ldq, B, cand, pos, loss_kind, label_smoothing, normalizer, n_cand_global,
+                      flags, loss_out, dE, nullptr, dQ, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+int okge_prefix_backward(const okge_tables *t, const okge_shard *sh, const okge_prefix_batch *batch, const float *dQ,
+                         int64_t ldq, const float *ent_rows, float *dE, float *dR, void *stream)
+{
+    okge_candidates none;
+    std::memset(&none, 0, sizeof(none));
+    none.n = 1; none.first_id = 0;
+    if (int rc = check_common(t, batch, &none)) return rc;
+    if (int rc = check_shard(t, sh)) return rc;
+    if (!dQ || !dE || !dR || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad prefix_backward arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PrefixDev p = to_dev(*batch, sh);
+    const int B = batch->n_po + batch->n_sp;
+    ScopedTimer tm("prefix_backward", st);
+    hipError_t e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, dQ, 1, okge_query_rows(B), (int)ldq, ent_rows,
+                                          dE, dR, nullptr, 0, nullptr, st);
+    if (e != hipSuccess) return fail_hip(e, "prefix_backward");
     return OKGE_OK;
 }
 

@@ -35,6 +35,7 @@ struct FusedArgs {
     int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero;
     float          y_pos, y_neg, inv_norm;
     int32_t        stagger;    // s_sleep units (64 clk) the second-resident workgroups wait before starting
+    int32_t        cand_col0;  // global column (candidate position) of local candidate 0: positives, dropout keys
     int32_t        loss_only;  // forward + loss only: no G store, no dC product, no write-back
     int32_t        ablate;     // diagnostic (OKGE_ABLATE): bit0 no score product, 1 no loss math, 2 no G store,
                                // 3 no dC product, 4 no candidate dropout/Cm store, 5 no dE write-back, 6 no Q staging
@@ -50,6 +51,7 @@ struct DqArgs {
 struct PrefixDev {
     const int32_t *po_rel, *po_obj, *sp_subj, *sp_rel;
     int32_t        n_po, n_sp;
+    int32_t        ent_lo, ent_hi;   // global entity ids [ent_lo, ent_hi) live in the local table (row = id - ent_lo)
     DropDev        drop_po_ent, drop_po_rel, drop_sp_ent, drop_sp_rel;
 };
 
@@ -61,11 +63,13 @@ size_t     fused32_shmem_bytes(int LDK);
 hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
-                                 int ldq, int Bpad, const int32_t *pos_col, int nnz, int32_t *tile_ptr, int tiles,
-                                 int tile_w, hipStream_t st);
+                                 int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
+                                 int tiles, int tile_w, int cand_col0, hipStream_t st);
+hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, hipStream_t st);
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
-                                  const float *slab, int nsplit, int Bpad, int ldq, float *dE, float *dR,
-                                  const double *loss_partials, int n_partials, double *loss_out, hipStream_t st);
+                                  const float *slab, int nsplit, int Bpad, int ldq, const float *ent_rows, float *dE,
+                                  float *dR, const double *loss_partials, int n_partials, double *loss_out,
+                                  hipStream_t st);
 hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
 hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, const int32_t *pos_row, int nnz,
                                float *row_lse, float *row_ysum, hipStream_t st);

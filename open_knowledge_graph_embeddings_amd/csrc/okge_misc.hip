@@ -13,48 +13,63 @@
 namespace okge {
 
 struct RowSrc {
-    int64_t ent, rel;
+    int64_t ent, rel;   // ent: row in the LOCAL entity table (global id - ent_lo); valid only if owned
     uint32_t pos;
-    bool sp;
+    bool sp, owned;
 };
 
+// Entity rows are sharded by id: this rank holds global ids [ent_lo, ent_hi) as local rows 0 .. ent_hi-ent_lo-1.
 __device__ __forceinline__ RowSrc row_source(const PrefixDev &p, int b)
 {
     RowSrc r;
+    int64_t gid;
     if (b < p.n_po) {
-        r.rel = p.po_rel[b]; r.ent = p.po_obj[b]; r.pos = (uint32_t)b; r.sp = false;
+        r.rel = p.po_rel[b]; gid = p.po_obj[b]; r.pos = (uint32_t)b; r.sp = false;
     } else {
         const int i = b - p.n_po;
-        r.ent = p.sp_subj[i]; r.rel = p.sp_rel[i]; r.pos = (uint32_t)i; r.sp = true;
+        gid = p.sp_subj[i]; r.rel = p.sp_rel[i]; r.pos = (uint32_t)i; r.sp = true;
     }
+    r.owned = gid >= p.ent_lo && gid < p.ent_hi;
+    r.ent = gid - p.ent_lo;
     return r;
 }
 
 __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                              int d, int scorer, const PrefixDev p,
                                                              float *__restrict__ Q, int ldq, int Bpad,
+                                                             float *__restrict__ ent_rows,
                                                              const int32_t *__restrict__ pos_col, int nnz,
-                                                             int32_t *__restrict__ tile_ptr, int tiles, int tile_w)
+                                                             int32_t *__restrict__ tile_ptr, int tiles, int tile_w,
+                                                             int cand_col0)
 {
     if ((int)blockIdx.x >= Bpad) {
         // extra workgroups: offsets of each candidate tile's positives in the column-sorted coordinate list
         const int t = ((int)blockIdx.x - Bpad) * 128 + threadIdx.x;
-        if (t <= tiles) tile_ptr[t] = lower_bound_i32(pos_col, nnz, t * tile_w);
+        if (t <= tiles) tile_ptr[t] = lower_bound_i32(pos_col, nnz, cand_col0 + t * tile_w);
         return;
     }
     const int b = blockIdx.x, B = p.n_po + p.n_sp;
     float *q = Q + (size_t)b * ldq;
-    if (b >= B) {
-        for (int k = threadIdx.x; k < ldq; k += blockDim.x) q[k] = 0.f;
+    float *er = ent_rows ? ent_rows + (size_t)b * ldq : nullptr;
+    RowSrc rs;
+    rs.owned = false;
+    if (b < B) rs = row_source(p, b);
+    if (!rs.owned) {       // padding row, or a prefix whose entity lives on another rank: contributes zero
+        for (int k = threadIdx.x; k < ldq; k += blockDim.x) {
+            q[k] = 0.f;
+            if (er) er[k] = 0.f;
+        }
         return;
     }
-    const RowSrc rs = row_source(p, b);
     const DropDev &de = rs.sp ? p.drop_sp_ent : p.drop_po_ent;
     const DropDev &dr = rs.sp ? p.drop_sp_rel : p.drop_po_rel;
     const float *e = E + rs.ent * d, *r = R + rs.rel * d;
     if (scorer == SC_DISTMULT) {
-        for (int k = threadIdx.x; k < d; k += blockDim.x)
-            q[k] = (e[k] * drop_mult1(de, rs.pos, k, d)) * (r[k] * drop_mult1(dr, rs.pos, k, d));
+        for (int k = threadIdx.x; k < d; k += blockDim.x) {
+            const float ev = e[k] * drop_mult1(de, rs.pos, k, d);
+            q[k] = ev * (r[k] * drop_mult1(dr, rs.pos, k, d));
+            if (er) er[k] = ev;
+        }
     } else {
         const int h = d >> 1;
         for (int k = threadIdx.x; k < h; k += blockDim.x) {
@@ -67,22 +82,45 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
                 q[k] = e1 * r1 + e2 * r2;
                 q[h + k] = e2 * r1 - e1 * r2;
             }
+            if (er) { er[k] = e1; er[h + k] = e2; }
         }
     }
-    for (int k = d + threadIdx.x; k < ldq; k += blockDim.x) q[k] = 0.f;
+    for (int k = d + threadIdx.x; k < ldq; k += blockDim.x) {
+        q[k] = 0.f;
+        if (er) er[k] = 0.f;
+    }
+}
+
+// dQ[b][k] = sum over candidate ranges of the dq_kernel slabs (sharded path: reduced before the all-reduce)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, int nsplit, int64_t n4,
+                                                          float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sidx = 0; sidx < nsplit; ++sidx) {
+        const float4 v = reinterpret_cast<const float4 *>(slab)[(size_t)sidx * n4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4 *>(out)[i] = acc;
 }
 
 __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                               int d, int scorer, const PrefixDev p,
                                                               const float *__restrict__ slab, int nsplit, int Bpad,
-                                                              int ldq, float *__restrict__ dE, float *__restrict__ dR)
+                                                              int ldq, const float *__restrict__ ent_rows,
+                                                              float *__restrict__ dE, float *__restrict__ dR)
 {
+    // ent_rows (sharded path): the already masked prefix entity rows of ALL prefixes, so every rank forms the full
+    // relation gradient; the entity gradient is scattered by the owner only.
     const int b = blockIdx.x;
     const RowSrc rs = row_source(p, b);
+    if (!ent_rows && !rs.owned) return;
     const DropDev &de = rs.sp ? p.drop_sp_ent : p.drop_po_ent;
     const DropDev &dr = rs.sp ? p.drop_sp_rel : p.drop_po_rel;
-    const float *e = E + rs.ent * d, *r = R + rs.rel * d;
-    float *ge = dE + rs.ent * d, *gr = dR + rs.rel * d;
+    const float *e = ent_rows ? ent_rows + (size_t)b * ldq : E + rs.ent * d, *r = R + rs.rel * d;
+    const bool e_masked = ent_rows != nullptr;
+    float *ge = dE + (rs.owned ? rs.ent : 0) * d, *gr = dR + rs.rel * d;
     const size_t split_stride = (size_t)Bpad * ldq;
     const float *sl = slab + (size_t)b * ldq;
     if (scorer == SC_DISTMULT) {
@@ -90,8 +128,8 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
             float dq = 0.f;
             for (int sidx = 0; sidx < nsplit; ++sidx) dq += sl[sidx * split_stride + k];
             const float me = drop_mult1(de, rs.pos, k, d), mr = drop_mult1(dr, rs.pos, k, d);
-            const float ev = e[k] * me, rv = r[k] * mr;
-            atomicAdd(ge + k, dq * rv * me);
+            const float ev = e_masked ? e[k] : e[k] * me, rv = r[k] * mr;
+            if (rs.owned) atomicAdd(ge + k, dq * rv * me);
             atomicAdd(gr + k, dq * ev * mr);
         }
         return;
@@ -105,7 +143,8 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
         }
         const float me1 = drop_mult1(de, rs.pos, k, d), me2 = drop_mult1(de, rs.pos, h + k, d);
         const float mr1 = drop_mult1(dr, rs.pos, k, d), mr2 = drop_mult1(dr, rs.pos, h + k, d);
-        const float e1 = e[k] * me1, e2 = e[h + k] * me2, r1 = r[k] * mr1, r2 = r[h + k] * mr2;
+        const float e1 = e_masked ? e[k] : e[k] * me1, e2 = e_masked ? e[h + k] : e[h + k] * me2;
+        const float r1 = r[k] * mr1, r2 = r[h + k] * mr2;
         float de1, de2, dr1, dr2;
         if (rs.sp) {
             de1 = q1 * r1 + q2 * r2;  de2 = -q1 * r2 + q2 * r1;
@@ -114,8 +153,10 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
             de1 = q1 * r1 - q2 * r2;  de2 = q1 * r2 + q2 * r1;
             dr1 = q1 * e1 + q2 * e2;  dr2 = q1 * e2 - q2 * e1;
         }
-        atomicAdd(ge + k, de1 * me1);
-        atomicAdd(ge + h + k, de2 * me2);
+        if (rs.owned) {
+            atomicAdd(ge + k, de1 * me1);
+            atomicAdd(ge + h + k, de2 * me2);
+        }
         atomicAdd(gr + k, dr1 * mr1);
         atomicAdd(gr + h + k, dr2 * mr2);
     }
@@ -170,20 +211,23 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v)
 __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                                   int d, int scorer, const PrefixDev p,
                                                                   const float *__restrict__ slab, int nsplit, int Bpad,
-                                                                  int ldq, float *__restrict__ dE, float *__restrict__ dR,
+                                                                  int ldq, const float *__restrict__ ent_rows,
+                                                                  float *__restrict__ dE, float *__restrict__ dR,
                                                                   const double *__restrict__ loss_partials,
                                                                   int n_partials, double *__restrict__ loss_out)
 {
     if (blockIdx.x == gridDim.x - 1) {
-        loss_reduce_block(loss_partials, n_partials, loss_out);
+        if (loss_partials) loss_reduce_block(loss_partials, n_partials, loss_out);
         return;
     }
     const int b = blockIdx.x, grp = threadIdx.x >> 2, sq = threadIdx.x & 3;
     const RowSrc rs = row_source(p, b);
+    if (!ent_rows && !rs.owned) return;
     const DropDev &de = rs.sp ? p.drop_sp_ent : p.drop_po_ent;
     const DropDev &dr = rs.sp ? p.drop_sp_rel : p.drop_po_rel;
-    const float *e = E + rs.ent * d, *r = R + rs.rel * d;
-    float *ge = dE + rs.ent * d, *gr = dR + rs.rel * d;
+    const float *e = ent_rows ? ent_rows + (size_t)b * ldq : E + rs.ent * d, *r = R + rs.rel * d;
+    const bool e_masked = ent_rows != nullptr;
+    float *ge = dE + (rs.owned ? rs.ent : 0) * d, *gr = dR + rs.rel * d;
     const size_t split_stride = (size_t)Bpad * ldq;
     const float *sl = slab + (size_t)b * ldq;
     const int s_lo = (nsplit * sq) >> 2, s_hi = (nsplit * (sq + 1)) >> 2;
@@ -217,9 +261,10 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
             const float4 dq = dq_sum(act ? k : 0, act);
             if (act && sq == 0) {
                 const float4 me = keep_mult4(de, rs.pos, k, d), mr = keep_mult4(dr, rs.pos, k, d);
-                const float4 ev = f4mul(*reinterpret_cast<const float4 *>(e + k), me);
+                float4 ev = *reinterpret_cast<const float4 *>(e + k);
+                if (!e_masked) ev = f4mul(ev, me);
                 const float4 rv = f4mul(*reinterpret_cast<const float4 *>(r + k), mr);
-                atomic_add4(ge + k, f4mul(f4mul(dq, rv), me));
+                if (rs.owned) atomic_add4(ge + k, f4mul(f4mul(dq, rv), me));
                 atomic_add4(gr + k, f4mul(f4mul(dq, ev), mr));
             }
         }
@@ -233,8 +278,8 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
         if (!(act && sq == 0)) continue;
         const float4 me1 = keep_mult4(de, rs.pos, k, d), me2 = keep_mult4(de, rs.pos, h + k, d);
         const float4 mr1 = keep_mult4(dr, rs.pos, k, d), mr2 = keep_mult4(dr, rs.pos, h + k, d);
-        const float4 e1 = f4mul(*reinterpret_cast<const float4 *>(e + k), me1);
-        const float4 e2 = f4mul(*reinterpret_cast<const float4 *>(e + h + k), me2);
+        float4 e1 = *reinterpret_cast<const float4 *>(e + k), e2 = *reinterpret_cast<const float4 *>(e + h + k);
+        if (!e_masked) { e1 = f4mul(e1, me1); e2 = f4mul(e2, me2); }
         const float4 r1 = f4mul(*reinterpret_cast<const float4 *>(r + k), mr1);
         const float4 r2 = f4mul(*reinterpret_cast<const float4 *>(r + h + k), mr2);
         float4 de1, de2, dr1, dr2;
@@ -245,8 +290,10 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
             de1 = f4fma(q1, r1, f4neg(f4mul(q2, r2)));    de2 = f4fma(q1, r2, f4mul(q2, r1));
             dr1 = f4fma(q1, e1, f4mul(q2, e2));           dr2 = f4fma(q1, e2, f4neg(f4mul(q2, e1)));
         }
-        atomic_add4(ge + k, f4mul(de1, me1));
-        atomic_add4(ge + h + k, f4mul(de2, me2));
+        if (rs.owned) {
+            atomic_add4(ge + k, f4mul(de1, me1));
+            atomic_add4(ge + h + k, f4mul(de2, me2));
+        }
         atomic_add4(gr + k, f4mul(dr1, mr1));
         atomic_add4(gr + h + k, f4mul(dr2, mr2));
     }
@@ -420,30 +467,40 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
 
 // ---- launchers -----------------------------------------------------------------------------------------
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
-                                 int ldq, int Bpad, const int32_t *pos_col, int nnz, int32_t *tile_ptr, int tiles,
-                                 int tile_w, hipStream_t st)
+                                 int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
+                                 int tiles, int tile_w, int cand_col0, hipStream_t st)
 {
-    if (Bpad <= 0) return hipSuccess;
     const int extra = tile_ptr ? (tiles + 1 + 127) / 128 : 0;
+    if (Bpad + extra <= 0) return hipSuccess;
     hipLaunchKernelGGL(encode_queries_kernel, dim3(Bpad + extra), dim3(128), 0, st, E, R, d, scorer, p, Q, ldq, Bpad,
-                       pos_col, nnz, tile_ptr, tiles, tile_w);
+                       ent_rows, pos_col, nnz, tile_ptr, tiles, tile_w, cand_col0);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, hipStream_t st)
+{
+    const int64_t n4 = n / 4;
+    if (n4 <= 0) return hipSuccess;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, nsplit, n4, out);
     return hipGetLastError();
 }
 
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
-                                  const float *slab, int nsplit, int Bpad, int ldq, float *dE, float *dR,
-                                  const double *loss_partials, int n_partials, double *loss_out, hipStream_t st)
+                                  const float *slab, int nsplit, int Bpad, int ldq, const float *ent_rows, float *dE,
+                                  float *dR, const double *loss_partials, int n_partials, double *loss_out,
+                                  hipStream_t st)
 {
     const int B = p.n_po + p.n_sp;
     if (B <= 0) return hipSuccess;
     const bool vec = scorer == SC_DISTMULT ? (d % 4 == 0) : (d % 8 == 0);
     if (vec) {
         hipLaunchKernelGGL(prefix_backward_vec_kernel, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
-                           nsplit, Bpad, ldq, dE, dR, loss_partials, n_partials, loss_out);
+                           nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out);
     } else {
         hipLaunchKernelGGL(prefix_backward_kernel, dim3(B), dim3(128), 0, st, E, R, d, scorer, p, slab, nsplit, Bpad, ldq,
-                           dE, dR);
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_partials, n_partials, loss_out);
+                           ent_rows, dE, dR);
+        if (loss_partials)
+            hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_partials, n_partials, loss_out);
     }
     return hipGetLastError();
 }

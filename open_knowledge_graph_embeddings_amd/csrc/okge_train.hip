@@ -36,7 +36,7 @@ namespace okge {
 template <int KB>
 __device__ __forceinline__ void load_cand_tile(float *Cs, uint8_t *keepb, float *Cm, const float *__restrict__ E,
                                                int d, const int32_t *__restrict__ cand_ids, int cand_first, int N,
-                                               int n0, const DropDev &drop, bool vec_ok, int tid)
+                                               int n0, const DropDev &drop, bool vec_ok, int tid, int cand_col0)
 {
     constexpr int LDK = lds_ld(16 * KB), NO = 2 * KB, NOIT = (NO + 7) / 8;
 #pragma unroll
@@ -72,7 +72,7 @@ __device__ __forceinline__ void load_cand_tile(float *Cs, uint8_t *keepb, float 
             if (o < NO) {
                 uint32_t bits = 0xFFu;
                 if (drop.enabled) {
-                    bits = (valid && k < d) ? drop_keep8(drop, (uint32_t)n, o, d) : 0u;
+                    bits = (valid && k < d) ? drop_keep8(drop, (uint32_t)(n + cand_col0), o, d) : 0u;
                     apply_keep4(v0[it], bits & 15u, drop.scale);
                     apply_keep4(v1[it], bits >> 4, drop.scale);
                 }
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
             qreg[it] = (b < b_end) ? *reinterpret_cast<const v4f *>(src + 16 * it) : (v4f){0.f, 0.f, 0.f, 0.f};
     };
     fetch_chunk(b_begin);
-    load_cand_tile<KB>(Cs, nullptr, nullptr, a.E, d, a.cand_ids, a.cand_first, a.N, n0, a.drop_c, vec_ok, tid);
+    load_cand_tile<KB>(Cs, nullptr, nullptr, a.E, d, a.cand_ids, a.cand_first, a.N, n0, a.drop_c, vec_ok, tid,
+                       a.cand_col0);
 
     for (int b0 = b_begin; b0 < b_end; b0 += BC) {
         // ---- phase A: park the prefetched chunk in LDS, prefetch the next chunk -------------------------------

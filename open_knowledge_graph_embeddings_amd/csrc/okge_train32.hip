@@ -120,7 +120,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
             if (o < NO) {
                 uint32_t bits = 0xFFu;
                 if (a.drop_c.enabled && !(a.ablate & 16)) {
-                    bits = (valid && k < d) ? drop_keep8(a.drop_c, (uint32_t)n, o, d) : 0u;
+                    bits = (valid && k < d) ? drop_keep8(a.drop_c, (uint32_t)(n + a.cand_col0), o, d) : 0u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v0[it][e] *= (bits >> e & 1u) ? a.drop_c.scale : 0.f;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
     const int pos_lo = a.tile_ptr[blockIdx.x], pos_hi = a.tile_ptr[blockIdx.x + 1];
     const int pos_cached = min(pos_hi - pos_lo, POS_CACHE);
     for (int i = tid; i < pos_cached; i += FUSED_THREADS)
-        posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - n0);
+        posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - a.cand_col0 - n0);
     __syncthreads();
 
     v4f dc[KB];                                      // dC[n = 16nbk + 4s + i][k = grad col(kbi, c)], rows of this half
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         }
         for (int p = pos_lo + POS_CACHE + tid; p < pos_hi; p += FUSED_THREADS) {      // overflow: rare
             const int row = a.pos_row[p] - b0;
-            if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (a.pos_col[p] - n0));
+            if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (a.pos_col[p] - a.cand_col0 - n0));
         }
         if (b0 + BC32 < b_end && !(a.ablate & 64)) fetch_chunk(b0 + BC32);
         __syncthreads();

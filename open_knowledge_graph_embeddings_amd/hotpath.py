@@ -81,6 +81,20 @@ class PrefixBatch:
         return 0 if self.pos_row is None else int(self.pos_row.numel())
 
 
+@dataclass
+class Shard:
+    """Rows [ent_lo, ent_hi) of the entity table live on this rank; cand_col0 = position of the first local
+    candidate in the un-sharded candidate list (include/okge.h, okge_shard)."""
+    ent_lo: int
+    ent_hi: int
+    cand_col0: int = 0
+
+    def c(self) -> N.Shard:
+        s = N.Shard()
+        s.ent_lo, s.ent_hi, s.cand_col0 = int(self.ent_lo), int(self.ent_hi), int(self.cand_col0)
+        return s
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -191,6 +205,56 @@ class HotPath:
             ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_forward_backward")
         del keep, prow, pcol
         return loss_out
+
+    # -- entity-sharded phases (include/okge.h: okge_encode_queries / okge_train_tiles / okge_prefix_backward) ----
+    def query_shape(self, B, d):
+        return int(self.lib.okge_query_rows(B)), int(self.lib.okge_query_ld(d))
+
+    def encode_queries(self, E_local, R, scorer, batch: PrefixBatch, shard: Shard, out=None):
+        """-> buffer [2][rows][ld]: out[0] = folded queries, out[1] = masked prefix entity rows; rows of prefixes
+        whose entity another rank owns are zero (the caller all-reduces the buffer)."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E_local, R, scorer)
+        rows, ld = self.query_shape(batch.B, t.d)
+        if out is None:
+            out = torch.empty((2, rows, ld), dtype=torch.float32, device=self.device)
+        sh = shard.c()
+        N.check(self.lib.okge_encode_queries(ctypes.byref(t), ctypes.byref(sh), ctypes.byref(pb), out[0].data_ptr(), ld,
+                                             out[1].data_ptr(), self._stream()), "okge_encode_queries")
+        del keep
+        return out
+
+    def train_tiles(self, E_local, R, scorer, Q, batch: PrefixBatch, shard: Shard, dE, dQ, n_cand_global, loss="bce",
+                    label_smoothing=0.0, normalizer=None, loss_out=None, grads_zero=False):
+        """Local candidates only: batch.cand_first / n_cand are LOCAL row indices, batch.pos_col GLOBAL columns."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E_local, R, scorer)
+        B, n = batch.B, c.n
+        ws = self.workspace(B, n, t.d)
+        pos = N.Positives()
+        prow, pcol = _i32(batch.pos_row, self.device), _i32(batch.pos_col, self.device)
+        pos.row, pos.col, pos.nnz = _ptr(prow), _ptr(pcol), batch.nnz
+        if normalizer is None:
+            normalizer = float(B) * float(n_cand_global)
+        if loss_out is None:
+            loss_out = torch.empty(1, dtype=torch.float64, device=self.device)
+        sh = shard.c()
+        N.check(self.lib.okge_train_tiles(
+            ctypes.byref(t), ctypes.byref(sh), Q.data_ptr(), Q.stride(0), B, ctypes.byref(c), ctypes.byref(pos),
+            N.LOSSES[loss] if isinstance(loss, str) else int(loss), float(label_smoothing), float(normalizer),
+            int(n_cand_global), N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0, loss_out.data_ptr(), dE.data_ptr(),
+            dQ.data_ptr(), ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_tiles")
+        del keep, prow, pcol
+        return loss_out
+
+    def prefix_backward(self, E_local, R, scorer, batch: PrefixBatch, shard: Shard, dQ, ent_rows, dE, dR):
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E_local, R, scorer)
+        sh = shard.c()
+        N.check(self.lib.okge_prefix_backward(ctypes.byref(t), ctypes.byref(sh), ctypes.byref(pb), dQ.data_ptr(),
+                                              dQ.stride(0), _ptr(ent_rows), dE.data_ptr(), dR.data_ptr(),
+                                              self._stream()), "okge_prefix_backward")
+        del keep
 
     def encode_rows(self, table, ids=None, first_id=0, n=None, drop: DropoutSpec = NO_DROP, out=None):
         """dropout(table[ids]) -> (n, d): LookupBaseRelationEmbedder._encode (model.py:455-480)."""

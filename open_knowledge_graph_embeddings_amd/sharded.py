@@ -1,0 +1,95 @@
+"""Training step with the entity table row-sharded over the GPUs of one node (one process per GPU,
+torch.distributed backend "nccl" = RCCL over xGMI).
+
+The reference has no counterpart (its only multi-device path is nn.DataParallel, openkge/trainer.py:143-145).
+Every rank processes the SAME batch of prefixes against ITS OWN slice of the candidate entities
+(tensor-parallel over the candidate axis); scores are independent per candidate and the BCE
+loss is separable, so one step needs exactly two small exchanges:
+
+    all-reduce(sum)  [2, B, d]  folded queries + masked prefix entity rows   (each row is non-zero on its owner)
+    all-reduce(sum)  [B, d]     partial query gradients dQ                    (+ the scalar loss, off the critical path)
+
+Entity rows, their dense gradients and Adagrad accumulators never leave their rank; the (small) relation table is
+replicated and its gradient is formed identically everywhere from the exchanged entity rows.
+
+The arithmetic is delegated to an `engine` (HotPath: the HIP kernels).  Tests inject a CPU engine so the exchange
+protocol can run under gloo without a GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import hotpath as H
+
+
+def shard_range(n_ent, world, rank):
+    """Contiguous, equal-sized row ranges (the last one may be shorter)."""
+    per = (n_ent + world - 1) // world
+    return min(rank * per, n_ent), min((rank + 1) * per, n_ent)
+
+
+class ShardedTrainStep:
+    def __init__(self, E_local, R, scorer, n_ent, min_entities_size=2, lr=0.3, weight_decay=1e-10, eps=1e-8,
+                 loss="bce", label_smoothing=0.0, input_dropout=0.0, relation_input_dropout=0.0, seed=0, engine=None,
+                 group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.ent_lo, self.ent_hi = shard_range(n_ent, self.world, self.rank)
+        if E_local.shape[0] != self.ent_hi - self.ent_lo:
+            raise ValueError("E_local must hold exactly this rank's rows")
+        if loss != "bce":
+            raise NotImplementedError("sharded training implements the BCE loss (KL needs cross-shard row statistics)")
+        self.E, self.R, self.scorer = E_local, R, scorer
+        self.n_ent, self.min_ent = n_ent, min_entities_size
+        self.lr, self.weight_decay, self.eps = lr, weight_decay, eps
+        self.loss, self.label_smoothing = loss, label_smoothing
+        self.input_dropout, self.relation_input_dropout, self.seed = input_dropout, relation_input_dropout, seed
+        self.engine = engine or H.HotPath(E_local.device)
+        self.dE, self.dR = torch.zeros_like(E_local), torch.zeros_like(R)
+        self.sumE, self.sumR = torch.zeros_like(E_local), torch.zeros_like(R)
+        self.steps = 0
+        self.loss_out = torch.zeros(1, dtype=torch.float64, device=E_local.device)
+        # local candidates of the 1-vs-all list (global ids min_ent .. n_ent-1)
+        c_lo = max(self.ent_lo, min_entities_size)
+        self.cand_first_local = c_lo - self.ent_lo
+        self.n_cand_local = max(0, self.ent_hi - c_lo)
+        self.n_cand_global = n_ent - min_entities_size
+        self.shard = H.Shard(self.ent_lo, self.ent_hi, c_lo - min_entities_size)
+
+    def _set_dropout(self, batch):
+        pe, pr, s, t = self.input_dropout, self.relation_input_dropout, self.seed, self.steps
+        batch.drop_cand = H.DropoutSpec(pe, s, H.STREAM_CAND, t)
+        batch.drop_po_ent = H.DropoutSpec(pe, s, H.STREAM_PO_ENT, t)
+        batch.drop_sp_ent = H.DropoutSpec(pe, s, H.STREAM_SP_ENT, t)
+        batch.drop_po_rel = H.DropoutSpec(pr, s, H.STREAM_PO_REL, t)
+        batch.drop_sp_rel = H.DropoutSpec(pr, s, H.STREAM_SP_REL, t)
+
+    def step(self, batch: H.PrefixBatch):
+        """`batch` is the GLOBAL batch (identical on every rank); 1-vs-all candidates; positives carry global columns."""
+        if batch.cand_ids is not None:
+            raise NotImplementedError("batch-shared sampled candidates are too few to shard: use replicas")
+        self.steps += 1
+        self._set_dropout(batch)
+        eng = self.engine
+        # 1. queries of the prefixes whose entity lives here; sum over ranks = all queries
+        qe = eng.encode_queries(self.E, self.R, self.scorer, batch, self.shard)
+        dist.all_reduce(qe, group=self.group)
+        # 2. local candidates: loss partial, local entity gradients, partial query gradients
+        local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
+                              pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=self.cand_first_local,
+                              n_cand=self.n_cand_local, drop_cand=batch.drop_cand)
+        dq = torch.empty_like(qe[0])
+        eng.train_tiles(self.E, self.R, self.scorer, qe[0], local, self.shard, self.dE, dq, self.n_cand_global,
+                        loss=self.loss, label_smoothing=self.label_smoothing,
+                        normalizer=float(batch.B) * float(self.n_cand_global), loss_out=self.loss_out, grads_zero=True)
+        dist.all_reduce(dq, group=self.group)
+        loss_work = dist.all_reduce(self.loss_out, group=self.group, async_op=True)
+        # 3. chain rule: entity rows by their owner, relation rows everywhere (identical)
+        eng.prefix_backward(self.E, self.R, self.scorer, batch, self.shard, dq, qe[1], self.dE, self.dR)
+        # 4. dense Adagrad on the local entity rows and on the replicated relation table
+        eng.adagrad2(self.E, self.dE, self.sumE, self.R, self.dR, self.sumR, self.lr, self.weight_decay, self.eps,
+                     zero_grad=True)
+        loss_work.wait()
+        return self.loss_out
