@@ -9,6 +9,11 @@
 A step = one pass of the hot path over one batch: gather+dropout, score all candidates, BCE loss,
 backward, dense Adagrad on both tables (what Trainer.compute_one_batch does, openkge/trainer.py:181-257).
 All inputs (tables, batches) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+N > 1: the entity table (and its Adagrad state) is row-sharded over the N GPUs and every rank scores the SAME
+global batch of 512*N prefixes against its own candidates (open_knowledge_graph_embeddings_amd/sharded.py:
+two small RCCL all-reduces per step).  Per-GPU work is constant in N ("weak" scaling); `value` counts each
+global batch once.
 """
 import argparse
 import json
@@ -99,6 +104,10 @@ def cpu_baseline(w, host_batches, budget_s=20.0):
 
 
 def main():
+    # RCCL (and friends) print banners on stdout; the contract is ONE JSON line there.  Everything else -> stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -123,14 +132,31 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
+    import dataclasses
     w = synthetic.WORKLOADS[args.workload]
     E, R = synthetic.make_tables(w, seed=1234)
-    # N > 1: independent data shards -- every rank trains its own replica on its own batches (see DESIGN.md
-    # "Multi-GPU"); the entity-sharded exchange path is exercised by tests/test_sharded.py.
-    host_batches = [synthetic.make_batch(w, seed=1234 + 1000 * rank + i) for i in range(N_BATCHES)]
-    Et, Rt = torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev)
-    step = FusedTrainStep(Et, Rt, w.scorer, loss=w.loss, lr=w.lr, input_dropout=w.input_dropout, seed=1234)
-    batches = [to_dev_batch(hb, w, dev) for hb in host_batches]
+    sharded = world > 1 or os.environ.get("OKGE_BENCH_FORCE_SHARDED") == "1"
+    if sharded:
+        if dist is None:                         # single-GPU rehearsal of the RCCL path
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep, shard_range
+        # global batch grows with the number of GPUs; identical on every rank (same seeds)
+        wg = dataclasses.replace(w, n_po=w.n_po * world, n_sp=w.n_sp * world)
+        host_batches = [synthetic.make_batch(wg, seed=1234 + i) for i in range(N_BATCHES)]
+        lo, hi = shard_range(w.n_ent, world, rank)
+        Et, Rt = torch.from_numpy(E[lo:hi].copy()).to(dev), torch.from_numpy(R).to(dev)
+        step = ShardedTrainStep(Et, Rt, w.scorer, w.n_ent, lr=w.lr, loss=w.loss, input_dropout=w.input_dropout, seed=1234)
+        batches = [to_dev_batch(hb, wg, dev) for hb in host_batches]
+        w_run = wg
+    else:
+        host_batches = [synthetic.make_batch(w, seed=1234 + i) for i in range(N_BATCHES)]
+        Et, Rt = torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev)
+        step = FusedTrainStep(Et, Rt, w.scorer, loss=w.loss, lr=w.lr, input_dropout=w.input_dropout, seed=1234)
+        batches = [to_dev_batch(hb, w, dev) for hb in host_batches]
+        w_run = w
     n_pos = [hb["n_pos"] for hb in host_batches]
 
     def barrier():
@@ -150,11 +176,9 @@ def main():
     elapsed = time.perf_counter() - t0
     loss_last = float(step.loss_out.item())
     if dist is not None:
-        tt = torch.tensor([elapsed, float(triples)], dtype=torch.float64, device=dev)
-        tmax = tt.clone()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        elapsed, triples = float(tmax[0].item()), float(tt[1].item())
+        elapsed = float(tmax[0].item())        # every rank processed the same global batches: count them once
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, separate pass ------------------
     roof = None
@@ -169,33 +193,36 @@ def main():
         eng.timing(False)
         tot_ms, cnt = per_kernel["fused_tile_train"]
         avg_s = tot_ms / cnt * 1e-3
-        flops = 4.0 * w.B * w.N * w.d                 # X = Q.C^T (2BNd) + dC = G^T.Q (2BNd) per launch
+        n_local = step.n_cand_local if sharded else w.N
+        flops = 4.0 * w_run.B * n_local * w.d         # X = Q.C^T (2BNd) + dC = G^T.Q (2BNd) per launch, this rank
         achieved = flops / avg_s / 1e12
         roof = {"bound": "mfma", "kernel": "fused_tile_kernel<train>", "achieved": achieved,
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                 "traffic": None, "avg_launch_us": avg_s * 1e6,
                 "kernels_us": {k: v[0] / v[1] * 1e3 for k, v in per_kernel.items()},
-                "step_flops_6BNd": 6.0 * w.B * w.N * w.d, "step_bytes_20Nd": 20.0 * w.N * w.d}
+                "step_flops_6BNd": 6.0 * w_run.B * n_local * w.d, "step_bytes_20Nd": 20.0 * n_local * w.d}
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not sharded:
         cpu = cpu_baseline(w, host_batches)
     line = {
         "metric": "training triples/sec (1-vs-all ComplEx d=200)", "value": triples / elapsed, "unit": "triples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{w.name}: FB15k-237-shaped |E|={w.n_ent} |R|={w.n_rel} d={w.d} ComplEx 1-vs-all "
-                               f"N={w.N}, B={w.B} ({w.n_po} po + {w.n_sp} sp), BCE, input_dropout {w.input_dropout}, "
-                               f"dense Adagrad lr {w.lr}",
-                   "global_batch": w.B * world, "parallelism": f"replicas x{world}" if world > 1 else "single"},
-        "prefixes_per_s": w.B * world * args.steps / elapsed, "last_loss_sum": loss_last,
+                               f"N={w.N}, B={w_run.B} ({w_run.n_po} po + {w_run.n_sp} sp), BCE, input_dropout "
+                               f"{w.input_dropout}, dense Adagrad lr {w.lr}",
+                   "global_batch": w_run.B,
+                   "parallelism": f"entity table row-sharded x{world}, batch 512 x{world}" if sharded else "single"},
+        "prefixes_per_s": w_run.B * args.steps / elapsed, "last_loss_sum": loss_last,
         "roofline": roof, "cpu_baseline": cpu,
     }
-    print(json.dumps(line))
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
