@@ -131,7 +131,7 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     // slot size padded to a width the tile kernels are instantiated for (zero columns are free of error,
     // not of time: d in (128, 208] runs as 208, etc.)
     const int kb = (d + 15) / 16;
-    g.KB = kb <= 4 ? 4 : kb <= 8 ? 8 : kb <= 13 ? 13 : 16;
+    g.KB = kb <= 4 ? 4 : kb <= 8 ? 8 : kb <= 13 ? 13 : kb <= 16 ? 16 : 32;
     g.D16 = 16 * g.KB;
     g.LDK = lds_ld(g.D16);
     g.ldq = g.D16;
@@ -150,8 +150,8 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     bs = std::min(bs, bblks);
     g.b_per_block = (bblks + bs - 1) / bs * BC;
     g.b_split = (g.Bpad + g.b_per_block - 1) / g.b_per_block;
-    // dQ kernel: (batch block, candidate range) workgroups, about two per CU
-    int ns = std::max(1, 256 / bblks);
+    // dQ kernel: (batch block, candidate range) workgroups, two per CU (measured: 512 beats 256 workgroups)
+    int ns = std::max(1, 512 / bblks);
     ns = env_int("OKGE_DQ_SPLIT", ns);
     ns = std::max(1, std::min(ns, g.tiles));
     if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
@@ -163,7 +163,7 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.off_Cm = off;    off += align_up((size_t)g.tiles * NT * g.D16 * sizeof(float), 256);
     g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
     g.off_loss = off;  off += align_up((size_t)2 * g.tiles * g.b_split * sizeof(double), 256);
-    g.off_stats = off; off += align_up((size_t)g.tiles * g.Bpad * 2 * sizeof(float), 256);
+    g.off_stats = off; off += align_up((size_t)2 * g.ktiles * g.Bpad * 2 * sizeof(float), 256);
     g.off_lse = off;   off += align_up((size_t)g.Bpad * sizeof(float), 256);
     g.off_ysum = off;  off += align_up((size_t)g.Bpad * sizeof(float), 256);
     g.total = off;
@@ -177,8 +177,7 @@ int check_common(const okge_tables *t, const okge_prefix_batch *b, const okge_ca
     if (t->d <= 0 || t->n_ent <= 0 || t->n_rel <= 0) return fail(OKGE_ERR_INVALID, "bad table shape");
     if (t->scorer != OKGE_COMPLEX && t->scorer != OKGE_DISTMULT) return fail(OKGE_ERR_INVALID, "unknown scorer");
     if (t->scorer == OKGE_COMPLEX && (t->d & 1)) return fail(OKGE_ERR_INVALID, "ComplEx needs an even slot size");
-    if (t->d > 256)
-        return fail(OKGE_ERR_UNSUPPORTED, "slot size > 256 is not supported by the fused tile kernel yet");
+    if (t->d > 512) return fail(OKGE_ERR_UNSUPPORTED, "slot sizes above 512 are not supported by the tile kernels");
     if (b->n_po < 0 || b->n_sp < 0 || b->n_po + b->n_sp <= 0) return fail(OKGE_ERR_INVALID, "empty batch");
     if (b->n_po > 0 && (!b->po_rel || !b->po_obj)) return fail(OKGE_ERR_INVALID, "null po ids");
     if (b->n_sp > 0 && (!b->sp_subj || !b->sp_rel)) return fail(OKGE_ERR_INVALID, "null sp ids");
@@ -242,7 +241,8 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     a.b_per_block = g.Bpad;     // rows are independent in score mode, but one pass per tile keeps C resident
     {
         ScopedTimer tm("fused_tile_score", st);
-        hipError_t e = launch_fused(MODE_SCORE, a, g.tiles, 1, st);
+        hipError_t e = g.KB <= 16 ? launch_fused(MODE_SCORE, a, g.tiles, 1, st)        // 64x64 cut
+                                  : launch_fused32(MODE_SCORE, a, g.ktiles, 1, st);    // slot sizes above 256
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     return OKGE_OK;
@@ -292,8 +292,6 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     a.tile_ptr = reinterpret_cast<const int32_t *>(ws + g.off_tptr);
     a.grads_zero = (flags & OKGE_TRAIN_GRADS_ZERO) ? 1 : 0;
     a.loss_only = loss_only ? 1 : 0;
-    a.stagger = env_int("OKGE_STAGGER", 0);
-    a.ablate = env_int("OKGE_ABLATE", 0);
     a.G = reinterpret_cast<float *>(ws + g.off_GT);
     a.Cm = reinterpret_cast<float *>(ws + g.off_Cm);
     a.dE = dE;
@@ -313,7 +311,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         s.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
         s.b_per_block = g.Bpad;
         ScopedTimer tm("fused_tile_score", st);
-        e = launch_fused(MODE_SCORE, s, g.tiles, 1, st);
+        e = g.KB <= 16 ? launch_fused(MODE_SCORE, s, g.tiles, 1, st) : launch_fused32(MODE_SCORE, s, g.ktiles, 1, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     if (loss_kind == OKGE_LOSS_KL) {
@@ -323,11 +321,12 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         s.b_per_block = g.Bpad;
         {
             ScopedTimer tm("fused_tile_stats", st);
-            e = launch_fused(MODE_STATS, s, g.tiles, 1, st);
+            e = g.KB <= 16 ? launch_fused(MODE_STATS, s, g.tiles, 1, st) : launch_fused32(MODE_STATS, s, g.ktiles, 1, st);
             if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
         }
         ScopedTimer tm("kl_row_stats", st);
-        e = launch_kl_row_stats(s.stats, g.tiles, g.B, g.Bpad, pos->row, pos->nnz,
+        // the 64x64 cut emits one (max, sum-exp) per 64-candidate tile, the 32x32 cut one per 16-candidate block
+        e = launch_kl_row_stats(s.stats, g.KB <= 16 ? g.tiles : 2 * g.ktiles, g.B, g.Bpad, pos->row, pos->nnz,
                                 reinterpret_cast<float *>(ws + g.off_lse), reinterpret_cast<float *>(ws + g.off_ysum), st);
         if (e != hipSuccess) return fail_hip(e, "kl_row_stats");
         a.row_lse = reinterpret_cast<const float *>(ws + g.off_lse);
@@ -435,7 +434,7 @@ int okge_train_tiles(const okge_tables *t, const okge_shard *sh, const float *Q,
                      void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!t || !cand || !t->E || t->d <= 0 || t->n_ent <= 0) return fail(OKGE_ERR_INVALID, "bad tables");
-    if (t->d > 256) return fail(OKGE_ERR_UNSUPPORTED, "slot size > 256 is not supported by the fused tile kernel yet");
+    if (t->d > 512) return fail(OKGE_ERR_UNSUPPORTED, "slot sizes above 512 are not supported by the tile kernels");
     if (int rc = check_shard(t, sh)) return rc;
     if (!Q || !dQ || B <= 0 || cand->n <= 0) return fail(OKGE_ERR_INVALID, "bad query block / candidates");
     if (!cand->ids && (cand->first_id < 0 || (int64_t)cand->first_id + cand->n > t->n_ent))

@@ -34,11 +34,8 @@ struct FusedArgs {
     DropDev        drop_c;
     int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero;
     float          y_pos, y_neg, inv_norm;
-    int32_t        stagger;    // s_sleep units (64 clk) the second-resident workgroups wait before starting
     int32_t        cand_col0;  // global column (candidate position) of local candidate 0: positives, dropout keys
     int32_t        loss_only;  // forward + loss only: no G store, no dC product, no write-back
-    int32_t        ablate;     // diagnostic (OKGE_ABLATE): bit0 no score product, 1 no loss math, 2 no G store,
-                               // 3 no dC product, 4 no candidate dropout/Cm store, 5 no dE write-back, 6 no Q staging
 };
 
 struct DqArgs {
@@ -59,7 +56,6 @@ size_t     fused_shmem_bytes(int LDK);
 size_t     dq_shmem_bytes(int LDK);
 hipError_t launch_fused(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st);
-size_t     fused32_shmem_bytes(int LDK);
 hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,

@@ -99,32 +99,45 @@ __device__ __forceinline__ void grad_product(v4f (&acc)[KB], const float *a_base
 {
     constexpr int LDK = lds_ld(16 * KB);
     constexpr int KQ = KB / 4, KR = KB % 4;
-    // b_base points at B[16*s][0]
+    // b_base points at B[16*s][0].  Operands of step t+1 are requested before the KB MFMAs of step t issue.
+    v4f pb[KQ > 0 ? KQ : 1], nb[KQ > 0 ? KQ : 1];
+    float pr[KR > 0 ? KR : 1], nr[KR > 0 ? KR : 1];
+    float pa, na = 0.f;
+    auto a_at = [&](int t) { return A_VEC ? a_base[t] : a_base[t * lda]; };   // A[out][16s + t]  |  A[16s + t][out]
 #pragma unroll
-    for (int t4 = 0; t4 < 4; ++t4) {
-        float av[4];
-        if (A_VEC) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(a_base + 4 * t4);   // A[out][16s + 4t4 ..+3]
-            av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
-        } else {
+    for (int kq = 0; kq < KQ; ++kq) pb[kq] = *reinterpret_cast<const v4f *>(b_base + 64 * kq + 4 * c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) av[j] = a_base[(4 * t4 + j) * lda];          // A[16s + t][out]
+    for (int r = 0; r < KR; ++r) pr[r] = b_base[64 * KQ + 16 * r + c];
+    pa = a_at(0);
+    __builtin_amdgcn_sched_group_barrier(0x100, KQ + KR + 1, 2);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (t + 1 < 16) {
+            const float *brow = b_base + (t + 1) * LDK;
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) nb[kq] = *reinterpret_cast<const v4f *>(brow + 64 * kq + 4 * c);
+#pragma unroll
+            for (int r = 0; r < KR; ++r) nr[r] = brow[64 * KQ + 16 * r + c];
+            na = a_at(t + 1);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float *brow = b_base + (4 * t4 + j) * LDK;
-#pragma unroll
-            for (int kq = 0; kq < KQ; ++kq) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(brow + 64 * kq + 4 * c);
-                acc[4 * kq + 0] = mfma16(av[j], b4.x, acc[4 * kq + 0]);
-                acc[4 * kq + 1] = mfma16(av[j], b4.y, acc[4 * kq + 1]);
-                acc[4 * kq + 2] = mfma16(av[j], b4.z, acc[4 * kq + 2]);
-                acc[4 * kq + 3] = mfma16(av[j], b4.w, acc[4 * kq + 3]);
-            }
-#pragma unroll
-            for (int r = 0; r < KR; ++r)
-                acc[4 * KQ + r] = mfma16(av[j], brow[64 * KQ + 16 * r + c], acc[4 * KQ + r]);
+        for (int kq = 0; kq < KQ; ++kq) {
+            acc[4 * kq + 0] = mfma16(pa, pb[kq][0], acc[4 * kq + 0]);
+            acc[4 * kq + 1] = mfma16(pa, pb[kq][1], acc[4 * kq + 1]);
+            acc[4 * kq + 2] = mfma16(pa, pb[kq][2], acc[4 * kq + 2]);
+            acc[4 * kq + 3] = mfma16(pa, pb[kq][3], acc[4 * kq + 3]);
         }
+#pragma unroll
+        for (int r = 0; r < KR; ++r) acc[4 * KQ + r] = mfma16(pa, pr[r], acc[4 * KQ + r]);
+        if (t + 1 < 16) {
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) pb[kq] = nb[kq];
+#pragma unroll
+            for (int r = 0; r < KR; ++r) pr[r] = nr[r];
+            pa = na;
+            __builtin_amdgcn_sched_group_barrier(0x100, KQ + KR + 1, 2);   // next step's ds_reads first
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, KB, 2);                // then this step's MFMAs
     }
 }
 
@@ -403,6 +416,7 @@ hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st)
         case 8:  return launch_dq_t<8>(a, grid_x, shmem, st);
         case 13: return launch_dq_t<13>(a, grid_x, shmem, st);
         case 16: return launch_dq_t<16>(a, grid_x, shmem, st);
+        case 32: return launch_dq_t<32>(a, grid_x, shmem, st);
         default: return hipErrorInvalidValue;
     }
 }

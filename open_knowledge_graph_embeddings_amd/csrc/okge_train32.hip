@@ -1,19 +1,29 @@
-// fused_tile32_kernel<KB, MODE>: the fused score -> loss -> dCand tile kernel (see okge_train.hip) re-cut so that
-// TWO workgroups are resident per CU: 32 candidates x 32 batch rows per step, ~60 KB LDS, <= 256 registers.
-// With one wave per SIMD (the 64x64 cut) every non-MFMA phase -- candidate gather, loss epilogue, LDS staging,
-// gradient write-back -- leaves the matrix pipe idle; with two independent workgroups per CU the hardware
-// interleaves one workgroup's MFMA phase with the other's VALU / memory phases.
+// fused_tile32_kernel<KB, MODE>: the fused score -> loss -> dCand tile kernel, cut so that TWO workgroups are
+// resident per CU (slot sizes up to 256): 32 candidates x 32 batch rows per step, ~60 KB LDS, <= 256 registers.
+// Replaces the reference's encode_obj(candidates) + 4 mm + cat + BCEWithLogits / log_softmax+KLDiv forward and the
+// mm / sigmoid half of autograd's backward (openkge/model.py:198-229,268-274,455-510; openkge/trainer.py:75-106,234).
 //
-// Wave roles (4 waves): nbk = w & 1 (16-candidate block), half = w >> 1.
-//   score product : wave computes the 16x16 block X[b-block half][n-block nbk] (two accumulator chains over k).
-//   dC product    : wave accumulates dC[n-block nbk][all 16*KB columns] over batch rows 16*half .. 16*half+15 of the
-//                   chunk; the two halves' partial sums are added in the write-back epilogue.
+// One workgroup (4 waves) owns 32 candidate entities: it gathers and drops them out ONCE into LDS (and hands the
+// masked rows to dq_kernel through `Cm`), then sweeps the batch's folded query rows in 32-row chunks.
+// Wave roles: nbk = w & 1 (16-candidate block), half = w >> 1 (16-row block of the chunk).
+//   score product : the wave's 16x16 block X[rows of half][candidates of nbk], two accumulator chains over k,
+//                   operands by ds_read_b128 requested one round ahead (v_mfma_f32_16x16x4_f32, exact fp32).
+//   loss epilogue : on the accumulator registers; label bit from an LDS bitmask (the tile's positives are cached
+//                   in LDS once), BCE-with-logits or KL-on-log-softmax gradient, scaled by 1/normalizer.
+//   dC product    : dC[candidates of nbk][all columns] += G^T . Q over the wave's 16 batch rows.
 // Register chaining: the MFMA result layout of the score block (lane column = candidate, register i of slot s =
 // batch row 4s+i) is exactly the A-operand layout the dC product needs (M index = candidate, contraction slot s,
 // step i = batch row 4s+i), so G = dLoss/dX never goes through LDS and no barrier separates the two products.
-// G leaves for dq_kernel straight from registers (one float4 per lane = 4 consecutive batch rows of one candidate)
-// as 64x64 transposed blocks  Gt[(T * nJ + J)][n_local (64)][b_local (64)],  T = 64-candidate chunk, J = 64-row block:
-// exactly the LDS image dq_kernel wants, so it stages the block with plain 16-byte copies.
+// G also leaves for dq_kernel straight from registers (one float4 per lane = 4 consecutive batch rows of one
+// candidate) as 64x64 transposed blocks  Gt[(T * nJ + J)][n_local (64)][b_local (64)],  T = 64-candidate chunk,
+// J = 64-row block: exactly the LDS image dq_kernel wants.
+// The two halves' dC partial sums are added in the write-back, which also applies the cached dropout flags.
+//
+// MODE_SCORE / MODE_STATS (used for slot sizes above 256, where the 64x64 score tile does not fit LDS) stop after
+// the score product and write X, or per-(16-candidate block, row) (max, sum-exp) for the KL loss.
+//
+// fp32 MFMA shares the SIMD's vector issue with VALU on gfx950, so the loop is MFMA cycles + VALU cycles; what the
+// second resident workgroup hides is latency (LDS, barriers, HBM), not arithmetic.
 #include <cstdio>
 #include <cstdlib>
 
@@ -24,38 +34,51 @@ namespace okge {
 
 constexpr int NT32 = 32, BC32 = 32;
 
+template <int KB> struct Tile32Cfg {
+    static constexpr int LDK = lds_ld(16 * KB);
+    static constexpr int NO = 2 * KB;                         // 8-column octets per row
+    static constexpr int KEEP_LD = NO < 32 ? 32 : NO;         // keep-flag bytes per row
+    static constexpr int WAVES_PER_SIMD = KB <= 16 ? 2 : 1;   // two workgroups per CU while the tiles fit
+};
+
+#ifdef OKGE_STAMPS
+// diagnostic build (tools/build_stamps.sh): workgroup placement + per-chunk phase timeline of wave 0
+#define TL_STAMP()                                                                                                 \
+    do {                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        unsigned long long t_;                                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                  \
+        if (a.stamps_dbg && threadIdx.x == 0 && tl_n < 80)                                                         \
+            a.stamps_dbg[(size_t)gridDim.x * gridDim.y * 4 + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 80 + tl_n] = t_; \
+        ++tl_n;                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    } while (0)
+#else
+#define TL_STAMP() do { } while (0)
+#endif
+
 template <int KB, int MODE>
-__global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const FusedArgs a)
+__global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void fused_tile32_kernel(const FusedArgs a)
 {
 #ifdef OKGE_STAMPS
     unsigned long long wg_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
     int tl_n = 0;
-#define TL_STAMP()                                                                                              \
-    do {                                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        unsigned long long t_;                                                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
-        if (a.stamps_dbg && threadIdx.x == 0 && tl_n < 80)                                                      \
-            a.stamps_dbg[(size_t)gridDim.x * gridDim.y * 4 + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 80 + tl_n] = t_; \
-        ++tl_n;                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-    } while (0)
-#else
-#define TL_STAMP() do { } while (0)
 #endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LDK = lds_ld(16 * KB);
+    using Cfg = Tile32Cfg<KB>;
+    constexpr int LDK = Cfg::LDK, NO = Cfg::NO, KEEP_LD = Cfg::KEEP_LD;
     constexpr int KQ = KB / 4, KR = KB % 4;
-    constexpr int NO = 2 * KB, NOIT = (NO + 7) / 8;      // 8-column octets per row
-    constexpr int NQ = 4 * KB, NQIT = (NQ + 7) / 8;      // float4 per row
+    constexpr int NOIT = (NO + 7) / 8;
+    constexpr int NQ = 4 * KB, NQIT = (NQ + 7) / 8;       // float4 per row
+    constexpr bool TRAIN = MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL;
     const int d = a.d;
     float *Cs = reinterpret_cast<float *>(smem);              // [32][LDK]   (end: dC stage of half 1)
     float *Qs = Cs + NT32 * LDK;                              // [32][LDK]   (end: dC stage of half 0)
     uint32_t *ybits2 = reinterpret_cast<uint32_t *>(Qs + BC32 * LDK);    // [2][32] label bits, double-buffered by chunk
     double *red = reinterpret_cast<double *>(ybits2 + 2 * BC32);         // [4]
-    uint8_t *keepb = reinterpret_cast<uint8_t *>(red + 4);               // [32][32] keep flags of the tile
-    uint32_t *posc = reinterpret_cast<uint32_t *>(keepb + NT32 * 32);    // [POS_CACHE] (row << 6 | col) of the tile
+    uint8_t *keepb = reinterpret_cast<uint8_t *>(red + 4);               // [32][KEEP_LD] keep flags of the tile
+    uint32_t *posc = reinterpret_cast<uint32_t *>(keepb + NT32 * KEEP_LD);   // [POS_CACHE] (row << 6 | col)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, s = lane >> 4;
     const int nbk = w & 1, half = w >> 1;
@@ -77,15 +100,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         }
     };
     fetch_chunk(b_begin);
-    // De-phase the two workgroups that share a CU (identical programs launched together otherwise run in
-    // lockstep: both in their MFMA phase, then both in their VALU/memory phase).  Speed only, never correctness.
-    {
-        const unsigned bid = blockIdx.x + blockIdx.y * gridDim.x;
-        const int mode = a.stagger >> 16, amount = a.stagger & 0xFFFF;
-        const bool late = mode == 0 ? bid >= 256 : mode == 1 ? (bid & 1) : mode == 2 ? ((bid >> 3) & 1) : ((bid >> 8) & 1);
-        if (amount > 0 && late)
-            for (int i = 0; i < amount; ++i) __builtin_amdgcn_s_sleep(1);
-    }
 
     // ---- candidate tile: gather, dropout, LDS; masked copy for dq_kernel ---------------------------------------
     {
@@ -94,7 +108,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         int64_t cid = 0;
         if (valid) cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
         const float *row = a.E + cid * d;
-        float *cm = (blockIdx.y == 0 && !a.loss_only) ? a.Cm + (size_t)n * (16 * KB) : nullptr;
+        float *cm = (TRAIN && blockIdx.y == 0 && !a.loss_only) ? a.Cm + (size_t)n * (16 * KB) : nullptr;
         v4f v0[NOIT], v1[NOIT];
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
             const int o = q8 + 8 * it, k = 8 * o;
             if (o < NO) {
                 uint32_t bits = 0xFFu;
-                if (a.drop_c.enabled && !(a.ablate & 16)) {
+                if (a.drop_c.enabled) {
                     bits = (valid && k < d) ? drop_keep8(a.drop_c, (uint32_t)(n + a.cand_col0), o, d) : 0u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -129,21 +143,25 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
                 }
                 *reinterpret_cast<v4f *>(Cs + r8 * LDK + k) = v0[it];
                 *reinterpret_cast<v4f *>(Cs + r8 * LDK + k + 4) = v1[it];
-                keepb[r8 * 32 + o] = (uint8_t)bits;
-                if (cm && !(a.ablate & 16)) {
+                if (TRAIN) keepb[r8 * KEEP_LD + o] = (uint8_t)bits;
+                if (cm) {
                     *reinterpret_cast<v4f *>(cm + k) = v0[it];
                     *reinterpret_cast<v4f *>(cm + k + 4) = v1[it];
                 }
             }
         }
     }
-    if (tid < 2 * BC32) ybits2[tid] = 0u;
     // positives of this tile: cached in LDS once (a global re-read per chunk costs an L2 round trip each time)
-    const int pos_lo = a.tile_ptr[blockIdx.x], pos_hi = a.tile_ptr[blockIdx.x + 1];
-    const int pos_cached = min(pos_hi - pos_lo, POS_CACHE);
-    for (int i = tid; i < pos_cached; i += FUSED_THREADS)
-        posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - a.cand_col0 - n0);
-    __syncthreads();
+    int pos_lo = 0, pos_hi = 0, pos_cached = 0;
+    if (TRAIN) {
+        if (tid < 2 * BC32) ybits2[tid] = 0u;
+        pos_lo = a.tile_ptr[blockIdx.x];
+        pos_hi = a.tile_ptr[blockIdx.x + 1];
+        pos_cached = min(pos_hi - pos_lo, POS_CACHE);
+        for (int i = tid; i < pos_cached; i += FUSED_THREADS)
+            posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - a.cand_col0 - n0);
+        __syncthreads();
+    }
 
     v4f dc[KB];                                      // dC[n = 16nbk + 4s + i][k = grad col(kbi, c)], rows of this half
 #pragma unroll
@@ -153,33 +171,33 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
     int par = 0;
     for (int b0 = b_begin; b0 < b_end; b0 += BC32, par ^= 1) {
         // ---- phase A: park the prefetched chunk, set label bits, prefetch the next chunk ------------------------
-        // (no barrier separates a wave's epilogue from its dC product any more, so the label bits are double-
-        //  buffered: this chunk's buffer was cleared one chunk ago, the previous chunk's buffer is cleared now)
+        // (no barrier separates a wave's epilogue from its dC product, so the label bits are double-buffered: this
+        //  chunk's buffer was cleared one chunk ago, the previous chunk's buffer is cleared now)
         uint32_t *ybits = ybits2 + par * BC32;
-        if (tid < BC32) ybits2[(par ^ 1) * BC32 + tid] = 0u;
-        if (!(a.ablate & 64)) {
 #pragma unroll
-            for (int it = 0; it < NQIT; ++it) {
-                const int q = q8 + 8 * it;
-                if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
+        for (int it = 0; it < NQIT; ++it) {
+            const int q = q8 + 8 * it;
+            if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
+        }
+        if (TRAIN) {
+            if (tid < BC32) ybits2[(par ^ 1) * BC32 + tid] = 0u;
+            for (int i = tid; i < pos_cached; i += FUSED_THREADS) {
+                const uint32_t v = posc[i];
+                const int row = (int)(v >> 6) - b0;
+                if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (v & 63u));
+            }
+            for (int p = pos_lo + POS_CACHE + tid; p < pos_hi; p += FUSED_THREADS) {      // overflow: rare
+                const int row = a.pos_row[p] - b0;
+                if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (a.pos_col[p] - a.cand_col0 - n0));
             }
         }
-        for (int i = tid; i < pos_cached; i += FUSED_THREADS) {
-            const uint32_t v = posc[i];
-            const int row = (int)(v >> 6) - b0;
-            if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (v & 63u));
-        }
-        for (int p = pos_lo + POS_CACHE + tid; p < pos_hi; p += FUSED_THREADS) {      // overflow: rare
-            const int row = a.pos_row[p] - b0;
-            if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (a.pos_col[p] - a.cand_col0 - n0));
-        }
-        if (b0 + BC32 < b_end && !(a.ablate & 64)) fetch_chunk(b0 + BC32);
+        if (b0 + BC32 < b_end) fetch_chunk(b0 + BC32);
         __syncthreads();
-
         TL_STAMP();   // [0] start of score product
-        // ---- phase B: X block (rows 16*half + 4s + i, columns 16*nbk + c) --------------------------------------
+
+        // ---- score block (rows 16*half + 4s + i, columns 16*nbk + c) -------------------------------------------
         v4f x0 = (v4f){0.f, 0.f, 0.f, 0.f}, x1 = (v4f){0.f, 0.f, 0.f, 0.f};
-        if (!(a.ablate & 1)) {
+        {
             // operands of round r+1 are requested before the 4 MFMAs of round r issue (LDS latency ~ one round)
             const float *qa = Qs + (16 * half + c) * LDK + 4 * s;
             const float *cb = Cs + (16 * nbk + c) * LDK + 4 * s;
@@ -204,6 +222,35 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         const v4f x = x0 + x1;
         TL_STAMP();   // [1] end of score product
 
+        if (MODE == MODE_SCORE) {
+            const int n = n0 + 16 * nbk + c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + 16 * half + 4 * s + i;
+                if (b < b_end && n < a.N) a.X[(size_t)b * a.ldx + n] = x[i];
+            }
+            __syncthreads();
+            continue;
+        }
+        if (MODE == MODE_STATS) {
+            // per row: max and sum-exp over this wave's 16 candidates -> stats[(2*tile + nbk)][row]
+            const bool nvalid = n0 + 16 * nbk + c < a.N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float m = nvalid ? x[i] : -INFINITY;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+                float se = nvalid ? __expf(x[i] - m) : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
+                const int b = b0 + 16 * half + 4 * s + i;
+                if (c == 0 && b < b_end)
+                    reinterpret_cast<float2 *>(a.stats)[(size_t)(2 * blockIdx.x + nbk) * a.Bpad + b] = make_float2(m, se);
+            }
+            __syncthreads();
+            continue;
+        }
+
         // B operands (query rows) of the dC product's first step: requested now, consumed after the epilogue
         const float *qb = Qs + (16 * half + 4 * s) * LDK;
         v4f pb[KQ > 0 ? KQ : 1];
@@ -226,9 +273,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
                 const bool valid = nvalid && (b0 + bl < b_end);
                 const bool pos = (ybits[bl] >> nl) & 1u;
                 float g, l;
-                if (a.ablate & 2) {
-                    g = xv; l = 0.f;
-                } else if (MODE == MODE_TRAIN_BCE) {
+                if (MODE == MODE_TRAIN_BCE) {
+                    // BCEWithLogits: max(x,0) - x*y + log1p(exp(-|x|)); d/dx = sigmoid(x) - y
+                    // v_exp_f32 / v_rcp_f32 / v_log_f32 (1 ulp each); 1 + e is in (1, 2]
                     const float y = pos ? a.y_pos : a.y_neg;
                     const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * LOG2E);
                     const float ope = 1.f + e;
@@ -237,6 +284,8 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
                     l = fmaxf(xv, 0.f) - xv * y + __builtin_amdgcn_logf(ope) * LN2;
                     g = sig - y;
                 } else {
+                    // KLDiv(sum)(log_softmax(x), y), y in {0,1} unnormalised (trainer.py:99-101):
+                    // loss = -sum_pos log_softmax; d/dx = softmax * sum_n y - y
                     const int b = min(b0 + bl, a.B - 1);
                     const float lsm = xv - a.row_lse[b];
                     l = pos ? -lsm : 0.f;
@@ -246,16 +295,16 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
                 g4[i] = valid ? g * a.inv_norm : 0.f;
             }
         }
-        // ---- G block -> HBM for dq_kernel: Gt[T][J][n_local][b_local], 4 consecutive batch rows per lane ----------
-        if (!(a.ablate & 4) && !a.loss_only) {
-            const int t = blockIdx.x, j = b0 >> 5;
-            const size_t blk = (size_t)(t >> 1) * (a.Bpad >> 6) + (j >> 1);
-            const int nl64 = 32 * (t & 1) + 16 * nbk + c, bl64 = 32 * (j & 1) + 16 * half + 4 * s;
-            *reinterpret_cast<v4f *>(a.G + blk * 4096 + nl64 * 64 + bl64) = g4;
-        }
         TL_STAMP();   // [2] start of dC product
-        // ---- dC += G^T . Q over this wave's 16 batch rows: A operand straight from g4 ----------------------------
-        if (!(a.ablate & 8) && !a.loss_only) {
+        if (!a.loss_only) {
+            // ---- G block -> HBM for dq_kernel: Gt[T][J][n_local][b_local], 4 consecutive batch rows per lane ------
+            {
+                const int t = blockIdx.x, j = b0 >> 5;
+                const size_t blk = (size_t)(t >> 1) * (a.Bpad >> 6) + (j >> 1);
+                const int nl64 = 32 * (t & 1) + 16 * nbk + c, bl64 = 32 * (j & 1) + 16 * half + 4 * s;
+                *reinterpret_cast<v4f *>(a.G + blk * 4096 + nl64 * 64 + bl64) = g4;
+            }
+            // ---- dC += G^T . Q over this wave's 16 batch rows: A operand straight from g4 ------------------------
             // slot s, step t  <->  batch row 16*half + 4s + t ; A = G[row][n = 16nbk + c] = g4[t], B = Q[row][columns]
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -292,28 +341,30 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
         __syncthreads();
     }
 
-    // ---- write-back: both halves stage their partial dC (half 0 -> Qs, half 1 -> Cs), then rows are summed,
-    //      masked with the cached dropout flags and added into dE -------------------------------------------------
-    {
-        float *stage = half == 0 ? Qs : Cs;
+    if (TRAIN) {
+        // ---- write-back: both halves stage their partial dC (half 0 -> Qs, half 1 -> Cs), then rows are summed,
+        //      masked with the cached dropout flags and added into dE ------------------------------------------------
+        if (!a.loss_only) {
+            float *stage = half == 0 ? Qs : Cs;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float *srow = stage + (16 * nbk + 4 * s + i) * LDK;
+            for (int i = 0; i < 4; ++i) {
+                float *srow = stage + (16 * nbk + 4 * s + i) * LDK;
 #pragma unroll
-            for (int kq = 0; kq < KQ; ++kq)
-                *reinterpret_cast<v4f *>(srow + 64 * kq + 4 * c) =
-                    (v4f){dc[4 * kq][i], dc[4 * kq + 1][i], dc[4 * kq + 2][i], dc[4 * kq + 3][i]};
+                for (int kq = 0; kq < KQ; ++kq)
+                    *reinterpret_cast<v4f *>(srow + 64 * kq + 4 * c) =
+                        (v4f){dc[4 * kq][i], dc[4 * kq + 1][i], dc[4 * kq + 2][i], dc[4 * kq + 3][i]};
 #pragma unroll
-            for (int r = 0; r < KR; ++r) srow[64 * KQ + 16 * r + c] = dc[4 * KQ + r][i];
+                for (int r = 0; r < KR; ++r) srow[64 * KQ + 16 * r + c] = dc[4 * KQ + r][i];
+            }
         }
-        const double ls = wave_sum((double)lsum);
-        if (lane == 0) red[w] = ls;
-    }
-    __syncthreads();
-    if (tid == 0) a.loss_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-    if (!(a.ablate & 32) && !a.loss_only) {
+        {
+            const double ls = wave_sum((double)lsum);
+            if (lane == 0) red[w] = ls;
+        }
+        __syncthreads();
+        if (tid == 0) a.loss_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
         const int n = n0 + r8;
-        if (n < a.N) {
+        if (!a.loss_only && n < a.N) {
             const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
             float *drow = a.dE + cid * d;
             const bool exclusive = gridDim.y == 1;
@@ -326,7 +377,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
                 v[1] = *reinterpret_cast<const v4f *>(Qs + r8 * LDK + k + 4) +
                        *reinterpret_cast<const v4f *>(Cs + r8 * LDK + k + 4);
                 if (a.drop_c.enabled) {
-                    const uint32_t bits = keepb[r8 * 32 + o];
+                    const uint32_t bits = keepb[r8 * KEEP_LD + o];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[0][e] *= (bits >> e & 1u) ? a.drop_c.scale : 0.f;
@@ -368,52 +419,57 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void fused_tile32_kernel(const Fu
 }
 
 // ---- launcher ---------------------------------------------------------------------------------------------------
-size_t fused32_shmem_bytes(int LDK)
+template <int KB>
+static size_t shmem32()
 {
-    return (size_t)(NT32 + BC32) * LDK * sizeof(float) + BC32 * sizeof(uint32_t) +
-           4 * sizeof(double) + NT32 * 32 + POS_CACHE * sizeof(uint32_t) + BC32 * sizeof(uint32_t);
+    using Cfg = Tile32Cfg<KB>;
+    return (size_t)(NT32 + BC32) * Cfg::LDK * sizeof(float) + 2 * BC32 * sizeof(uint32_t) + 4 * sizeof(double) +
+           NT32 * Cfg::KEEP_LD + POS_CACHE * sizeof(uint32_t);
 }
 
 template <int KB, int MODE>
-static hipError_t launch32_t(const FusedArgs &a, dim3 grid, size_t shmem, hipStream_t st)
+static hipError_t launch32_t(const FusedArgs &a, dim3 grid, hipStream_t st)
 {
     auto k = fused_tile32_kernel<KB, MODE>;
-    static size_t configured = 0;
-    if (shmem > configured) {
+    const size_t shmem = shmem32<KB>();
+    static bool configured = false;
+    if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return e;
-        configured = shmem;
+        configured = true;
     }
     if (std::getenv("OKGE_DEBUG")) {
         int nb = -1;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), FUSED_THREADS, shmem);
-        hipFuncAttributes fa;
-        (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k));
-        fprintf(stderr, "[okge] fused_tile32<%d>: occupancy %d blocks/CU (err %d), dyn LDS %zu, static LDS %zu, regs %d, grid %ux%u\n",
-                KB, nb, (int)e, shmem, (size_t)fa.sharedSizeBytes, fa.numRegs, grid.x, grid.y);
+        fprintf(stderr, "[okge] fused_tile32<%d,%d>: occupancy %d blocks/CU (err %d), dyn LDS %zu, grid %ux%u\n", KB, MODE,
+                nb, (int)e, shmem, grid.x, grid.y);
     }
     hipLaunchKernelGGL(k, grid, dim3(FUSED_THREADS), shmem, st, a);
     return hipGetLastError();
 }
 
 template <int KB>
-static hipError_t launch32_m(int mode, const FusedArgs &a, dim3 grid, size_t shmem, hipStream_t st)
+static hipError_t launch32_m(int mode, const FusedArgs &a, dim3 grid, hipStream_t st)
 {
-    return mode == MODE_TRAIN_KL ? launch32_t<KB, MODE_TRAIN_KL>(a, grid, shmem, st)
-                                 : launch32_t<KB, MODE_TRAIN_BCE>(a, grid, shmem, st);
+    switch (mode) {
+        case MODE_TRAIN_BCE: return launch32_t<KB, MODE_TRAIN_BCE>(a, grid, st);
+        case MODE_TRAIN_KL:  return launch32_t<KB, MODE_TRAIN_KL>(a, grid, st);
+        case MODE_SCORE:     return launch32_t<KB, MODE_SCORE>(a, grid, st);
+        default:             return launch32_t<KB, MODE_STATS>(a, grid, st);
+    }
 }
 
-// train modes only; grid_x = number of 32-candidate tiles (even, so every 64-wide chunk dq_kernel reads is written)
+// grid_x = number of 32-candidate tiles (even, so every 64-wide chunk dq_kernel reads is written)
 hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st)
 {
     const dim3 grid(grid_x, grid_y);
-    const size_t shmem = fused32_shmem_bytes(a.LDK);
     switch (a.KB) {
-        case 4:  return launch32_m<4>(mode, a, grid, shmem, st);
-        case 8:  return launch32_m<8>(mode, a, grid, shmem, st);
-        case 13: return launch32_m<13>(mode, a, grid, shmem, st);
-        case 16: return launch32_m<16>(mode, a, grid, shmem, st);
+        case 4:  return launch32_m<4>(mode, a, grid, st);
+        case 8:  return launch32_m<8>(mode, a, grid, st);
+        case 13: return launch32_m<13>(mode, a, grid, st);
+        case 16: return launch32_m<16>(mode, a, grid, st);
+        case 32: return launch32_m<32>(mode, a, grid, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -236,6 +236,9 @@ CASES = [
     ("complex", 5000, 50, 128, 100, 156, None, "bce", 0.0),
     ("distmult", 200, 5, 17, 3, 2, None, "bce", 0.0),          # odd slot size: scalar (non-float4) paths
     ("complex", 150, 5, 6, 2, 2, 1, "bce", 0.0),               # a single candidate
+    ("distmult", 2000, 30, 512, 70, 61, 700, "bce", 0.0),      # slot sizes above 256: the KB=32 instantiations
+    ("complex", 900, 20, 320, 33, 40, None, "kl", 0.0),
+    ("complex", 700, 11, 512, 40, 0, None, "bce", 0.1),
 ]
 
 
@@ -305,6 +308,30 @@ def test_philox_dropout_matches_oracle_masks(hp, scorer):
     assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
     np.testing.assert_allclose(dE.cpu().numpy(), ref["dE"], rtol=0, atol=3e-5 * np.abs(ref["dE"]).max())
     np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
+
+
+def test_full_size_distmult_d512_sampled(hp):
+    """configs[2]: FB15k-237 LookupDistmultRelationModel d=512, B=512, batch-shared sampled candidates N=10 000."""
+    n_ent, n_rel, d = 14543, 239, 512
+    E, R, z, cand, y = random_problem(4321, n_ent, n_rel, d, 256, 256, 10000, max_pos=6)
+    E *= 0.3
+    ref = oracle_step("distmult", E, R, z, cand, y)
+    Et, Rt = dev(E), dev(R)
+    batch = make_batch(z, cand, n_ent, labels=y)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = hp.forward_backward(Et, Rt, "distmult", batch, dE, dR)
+    out = hp.score(Et, Rt, "distmult", batch).cpu().numpy()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out, ref["outputs"], rtol=0, atol=SCORE_ATOL)
+    assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+    np.testing.assert_allclose(dE.cpu().numpy(), ref["dE"], rtol=0, atol=3e-5 * np.abs(ref["dE"]).max())
+    np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
+    # rows outside the sampled candidate set and outside the prefixes get no gradient
+    touched = np.zeros(n_ent, bool)
+    touched[cand] = True
+    touched[z["po_obj"]] = True
+    touched[z["sp_subj"]] = True
+    assert not dE.cpu().numpy()[~touched].any()
 
 
 # ------------------------------------------------------------------------------- BASELINE.json full size
