@@ -196,11 +196,44 @@ def main():
         n_local = step.n_cand_local if sharded else w.N
         flops = 4.0 * w_run.B * n_local * w.d         # X = Q.C^T (2BNd) + dC = G^T.Q (2BNd) per launch, this rank
         achieved = flops / avg_s / 1e12
-        roof = {"bound": "mfma", "kernel": "fused_tile_kernel<train>", "achieved": achieved,
+        # HBM bytes per launch of that kernel from the committed PMC passes of this same command
+        # (tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled as the gfx950 guide says)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and not sharded and args.workload == "S-FB":
+            tj = json.load(open(tpath))
+            hit = [v for k, v in tj.items() if k.startswith("fused_tile32_kernel")]
+            if hit:
+                traffic = hit[0]["hbm_bytes_per_launch"]
+        roof = {"bound": "mfma", "kernel": "fused_tile32_kernel<train>", "achieved": achieved,
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None, "avg_launch_us": avg_s * 1e6,
+                "traffic": traffic, "avg_launch_us": avg_s * 1e6,
                 "kernels_us": {k: v[0] / v[1] * 1e3 for k, v in per_kernel.items()},
                 "step_flops_6BNd": 6.0 * w_run.B * n_local * w.d, "step_bytes_20Nd": 20.0 * n_local * w.d}
+
+    # ---- evaluation leg (single GPU): score every candidate + filtered ranks (dataset.py:423-446) --------------
+    ev = None
+    if rank == 0 and not sharded:
+        hb = synthetic.make_eval_batch(w, seed=777)
+        eb = to_dev_batch(hb, w, dev)
+        t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+        csr = [t(hb[k]) for k in ("filt_ptr", "filt_col", "row_ptr", "grp_ptr", "ids")]
+        eng = step.engine
+        scores = eng.score(Et, Rt, w.scorer, eb)
+        for _ in range(3):
+            eng.score(Et, Rt, w.scorer, eb, out=scores)
+            ranks = eng.filtered_ranks(scores, *csr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_it = 30
+        for _ in range(n_it):
+            eng.score(Et, Rt, w.scorer, eb, out=scores)
+            ranks = eng.filtered_ranks(scores, *csr)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        r = ranks.cpu().numpy()
+        ev = {"ms_per_batch": 1e3 * el / n_it, "prefixes_per_s": w.B * n_it / el, "groups": int(r.shape[0]),
+              "mrr_random_init": float((1.0 / (r + 1.0)).mean())}
 
     if rank != 0:
         if dist is not None:
@@ -219,7 +252,7 @@ def main():
                    "global_batch": w_run.B,
                    "parallelism": f"entity table row-sharded x{world}, batch 512 x{world}" if sharded else "single"},
         "prefixes_per_s": w_run.B * args.steps / elapsed, "last_loss_sum": loss_last,
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "eval": ev,
     }
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())

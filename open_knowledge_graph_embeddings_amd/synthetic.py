@@ -78,3 +78,24 @@ def dense_labels(batch, B, N):
     y = np.zeros((B, N), np.float32)
     y[batch["pos_row"], batch["pos_col"]] = 1.0
     return y
+
+
+def make_eval_batch(w: Workload, seed):
+    """Evaluation batch: like make_batch, plus answer groups (one mention group per positive; FB15k-237 has
+    single-mention entities) and an all-splits filter = the positives plus ~2 answers from other splits per row
+    (dataset.py:520-565, :921-927).  CSR arrays: row_ptr/grp_ptr/ids for groups, filt_ptr/filt_col for filters."""
+    b = make_batch(w, seed)
+    rng = np.random.default_rng(seed + 99)
+    order = np.lexsort((b["pos_col"], b["pos_row"]))                   # by row, then column
+    rows, cols = b["pos_row"][order].astype(np.int64), b["pos_col"][order].astype(np.int64)
+    counts = np.bincount(rows, minlength=w.B)
+    b["row_ptr"] = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    b["grp_ptr"] = np.arange(len(cols) + 1, dtype=np.int64)            # one id per group
+    b["ids"] = cols.astype(np.int32)
+    extra_rows = np.repeat(np.arange(w.B, dtype=np.int64), 2)
+    extra_cols = rng.integers(0, w.N, extra_rows.shape[0]).astype(np.int64)
+    key = np.unique(np.concatenate([rows, extra_rows]) * w.N + np.concatenate([cols, extra_cols]))
+    frow, fcol = key // w.N, key % w.N
+    b["filt_ptr"] = np.concatenate([[0], np.cumsum(np.bincount(frow, minlength=w.B))]).astype(np.int64)
+    b["filt_col"] = fcol.astype(np.int32)
+    return b
