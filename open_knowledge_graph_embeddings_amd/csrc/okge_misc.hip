@@ -436,7 +436,23 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
         int gt[RANK_GROUPS], eq[RANK_GROUPS];
 #pragma unroll
         for (int j = 0; j < RANK_GROUPS; ++j) { t[j] = tv[j]; gt[j] = 0; eq[j] = 0; }
-        for (int n = tid; n < N; n += 256) {
+        // row sweep: 16-byte loads, two in flight per thread (HBM-bound: the row is read once per 8 groups)
+        const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
+        const int n4 = vec ? (N >> 2) : 0;
+        const float4 *row4 = reinterpret_cast<const float4 *>(row);
+        for (int i = tid; i < n4; i += 512) {
+            const float4 xa = row4[i];
+            const bool has_b = i + 256 < n4;
+            const float4 xb = has_b ? row4[i + 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e >= 4 && !has_b) break;
+#pragma unroll
+                for (int j = 0; j < RANK_GROUPS; ++j) { gt[j] += xs[e] > t[j]; eq[j] += xs[e] == t[j]; }
+            }
+        }
+        for (int n = 4 * n4 + tid; n < N; n += 256) {
             const float x = row[n];
 #pragma unroll
             for (int j = 0; j < RANK_GROUPS; ++j) { gt[j] += x > t[j]; eq[j] += x == t[j]; }

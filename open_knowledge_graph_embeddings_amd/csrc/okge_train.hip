@@ -191,18 +191,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) x[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
         {
+            // operands of round r+1 are requested before the 16 MFMAs of round r issue
             const float *qa = Qs + (16 * w + c) * LDK + 4 * s;
             const float *cb = Cs + c * LDK + 4 * s;
+            v4f av = *reinterpret_cast<const v4f *>(qa), bv[4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) bv[nb] = *reinterpret_cast<const v4f *>(cb + 16 * nb * LDK);
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
 #pragma unroll
             for (int r = 0; r < KB; ++r) {
-                const v4f av = *reinterpret_cast<const v4f *>(qa + 16 * r);
-                v4f bv[4];
+                v4f an = av, bn[4] = {bv[0], bv[1], bv[2], bv[3]};
+                if (r + 1 < KB) {
+                    an = *reinterpret_cast<const v4f *>(qa + 16 * (r + 1));
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) bv[nb] = *reinterpret_cast<const v4f *>(cb + 16 * nb * LDK + 16 * r);
+                    for (int nb = 0; nb < 4; ++nb) bn[nb] = *reinterpret_cast<const v4f *>(cb + 16 * nb * LDK + 16 * (r + 1));
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb) x[nb] = mfma16(av[j], bv[nb][j], x[nb]);
+                av = an;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) bv[nb] = bn[nb];
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);    // 5 ds_read (next round)
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMA  (this round)
             }
         }
         // lane holds X[b = b0 + 16w + 4s + i][n = n0 + 16nb + c] in x[nb][i]
