@@ -408,6 +408,52 @@ __global__ __launch_bounds__(256) void adagrad2_kernel(const AdagradSeg a, const
 
 constexpr int RANK_GROUPS = 8;
 
+// Count, for NG answer groups of one row at once, how many (filter-corrected) scores are greater than / equal to
+// each group's true score.  NG is the compile-time number of live groups (1, 2, 4 or 8): the sweep is VALU-bound
+// on the compares, and most rows have one or two groups.
+template <int NG>
+__device__ __forceinline__ void rank_sweep(const float *__restrict__ row, int64_t ld_is_vec, int N,
+                                           const int32_t *__restrict__ filt_col, int64_t f_lo, int64_t f_hi,
+                                           const float *tv, int tid, int (&gt)[RANK_GROUPS], int (&eq)[RANK_GROUPS])
+{
+    float t[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) t[j] = tv[j];
+    int g[NG], e[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) { g[j] = 0; e[j] = 0; }
+    const int n4 = ld_is_vec ? (N >> 2) : 0;
+    const float4 *row4 = reinterpret_cast<const float4 *>(row);
+    for (int i = tid; i < n4; i += 512) {                       // 16-byte loads, two in flight per thread
+        const float4 xa = row4[i];
+        const bool has_b = i + 256 < n4;
+        const float4 xb = has_b ? row4[i + 256] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= 4 && !has_b) break;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { g[j] += xs[k] > t[j]; e[j] += xs[k] == t[j]; }
+        }
+    }
+    for (int n = 4 * n4 + tid; n < N; n += 256) {
+        const float x = row[n];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { g[j] += x > t[j]; e[j] += x == t[j]; }
+    }
+    // filtered positions count as -1e8 instead of their score (dataset.py:441)
+    for (int64_t f = f_lo + tid; f < f_hi; f += 256) {
+        const float x = row[filt_col[f]];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            g[j] += (-1e8f > t[j]) - (x > t[j]);
+            e[j] += (-1e8f == t[j]) - (x == t[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RANK_GROUPS; ++j) { gt[j] = j < NG ? g[j < NG ? j : 0] : 0; eq[j] = j < NG ? e[j < NG ? j : 0] : 0; }
+}
+
 __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ scores, int64_t ld, int N,
                                                     const int64_t *__restrict__ filt_ptr,
                                                     const int32_t *__restrict__ filt_col,
@@ -421,6 +467,7 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
     const float *row = scores + (size_t)b * ld;
     const int64_t g_lo = row_ptr[b], g_hi = row_ptr[b + 1];
     const int64_t f_lo = filt_ptr[b], f_hi = filt_ptr[b + 1];
+    const int64_t vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
     for (int64_t g0 = g_lo; g0 < g_hi; g0 += RANK_GROUPS) {
         const int ng = (int)min((int64_t)RANK_GROUPS, g_hi - g0);
         if (tid < RANK_GROUPS) {
@@ -432,40 +479,11 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
             tv[tid] = t;
         }
         __syncthreads();
-        float t[RANK_GROUPS];
         int gt[RANK_GROUPS], eq[RANK_GROUPS];
-#pragma unroll
-        for (int j = 0; j < RANK_GROUPS; ++j) { t[j] = tv[j]; gt[j] = 0; eq[j] = 0; }
-        // row sweep: 16-byte loads, two in flight per thread (HBM-bound: the row is read once per 8 groups)
-        const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
-        const int n4 = vec ? (N >> 2) : 0;
-        const float4 *row4 = reinterpret_cast<const float4 *>(row);
-        for (int i = tid; i < n4; i += 512) {
-            const float4 xa = row4[i];
-            const bool has_b = i + 256 < n4;
-            const float4 xb = has_b ? row4[i + 256] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (e >= 4 && !has_b) break;
-#pragma unroll
-                for (int j = 0; j < RANK_GROUPS; ++j) { gt[j] += xs[e] > t[j]; eq[j] += xs[e] == t[j]; }
-            }
-        }
-        for (int n = 4 * n4 + tid; n < N; n += 256) {
-            const float x = row[n];
-#pragma unroll
-            for (int j = 0; j < RANK_GROUPS; ++j) { gt[j] += x > t[j]; eq[j] += x == t[j]; }
-        }
-        // filtered positions count as -1e8 instead of their score (dataset.py:441)
-        for (int64_t f = f_lo + tid; f < f_hi; f += 256) {
-            const float x = row[filt_col[f]];
-#pragma unroll
-            for (int j = 0; j < RANK_GROUPS; ++j) {
-                gt[j] += (-1e8f > t[j]) - (x > t[j]);
-                eq[j] += (-1e8f == t[j]) - (x == t[j]);
-            }
-        }
+        if (ng == 1)      rank_sweep<1>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
+        else if (ng == 2) rank_sweep<2>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
+        else if (ng <= 4) rank_sweep<4>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
+        else              rank_sweep<8>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
 #pragma unroll
         for (int j = 0; j < RANK_GROUPS; ++j) {
             const int a = wave_sum(gt[j]), e = wave_sum(eq[j]);

@@ -198,25 +198,31 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         // ---- score block (rows 16*half + 4s + i, columns 16*nbk + c) -------------------------------------------
         v4f x0 = (v4f){0.f, 0.f, 0.f, 0.f}, x1 = (v4f){0.f, 0.f, 0.f, 0.f};
         {
-            // operands of round r+1 are requested before the 4 MFMAs of round r issue (LDS latency ~ one round)
+            // operands are requested TWO rounds ahead: one round is 4 MFMAs = 128 cycles, about one LDS round trip
             const float *qa = Qs + (16 * half + c) * LDK + 4 * s;
             const float *cb = Cs + (16 * nbk + c) * LDK + 4 * s;
-            v4f av = *reinterpret_cast<const v4f *>(qa), bv = *reinterpret_cast<const v4f *>(cb);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // round 0 operands
+            v4f a0 = *reinterpret_cast<const v4f *>(qa), b0v = *reinterpret_cast<const v4f *>(cb);
+            v4f a1 = a0, b1v = b0v;
+            if (KB > 1) {
+                a1 = *reinterpret_cast<const v4f *>(qa + 16);
+                b1v = *reinterpret_cast<const v4f *>(cb + 16);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, KB > 1 ? 4 : 2, 0);   // rounds 0 and 1 operands
 #pragma unroll
             for (int r = 0; r < KB; ++r) {
-                v4f an = av, bn = bv;
-                if (r + 1 < KB) {
-                    an = *reinterpret_cast<const v4f *>(qa + 16 * (r + 1));
-                    bn = *reinterpret_cast<const v4f *>(cb + 16 * (r + 1));
+                v4f a2 = a1, b2v = b1v;
+                if (r + 2 < KB) {
+                    a2 = *reinterpret_cast<const v4f *>(qa + 16 * (r + 2));
+                    b2v = *reinterpret_cast<const v4f *>(cb + 16 * (r + 2));
                 }
-                x0 = mfma16(av[0], bv[0], x0);
-                x1 = mfma16(av[1], bv[1], x1);
-                x0 = mfma16(av[2], bv[2], x0);
-                x1 = mfma16(av[3], bv[3], x1);
-                av = an; bv = bn;
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 ds_read (next round)
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA   (this round)
+                x0 = mfma16(a0[0], b0v[0], x0);
+                x1 = mfma16(a0[1], b0v[1], x1);
+                x0 = mfma16(a0[2], b0v[2], x0);
+                x1 = mfma16(a0[3], b0v[3], x1);
+                a0 = a1; b0v = b1v;
+                a1 = a2; b1v = b2v;
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 ds_read (round r+2)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA   (round r)
             }
         }
         const v4f x = x0 + x1;
