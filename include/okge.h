@@ -150,8 +150,12 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
  *   3. okge_prefix_backward : chain rule; entity gradients scattered by the owner, relation gradients formed
  *                             identically on every rank from ent_rows.
  * cand_col0 = position of the first local candidate in the un-sharded candidate list: positives keep their
- * global columns and dropout masks are identical to the single-device run.  BCE only (the KL loss would need
- * per-row max / sum-exp exchanged between the ranks). */
+ * global columns and dropout masks are identical to the single-device run.
+ * KL loss: softmax runs over ALL candidates, so between 1 and 2 each rank calls okge_row_logsumexp on its local
+ * candidates, the B values are exchanged (all-gather, log-sum-exp over ranks) and the result goes to
+ * okge_train_tiles as `row_lse` (null for BCE).
+ * Evaluation: okge_score_queries on the local candidates, okge_group_true_scores
+ * -> all-reduce(max), okge_rank_counts -> all-reduce(sum); rank = #greater + #equal / 2 (dataset.py:441-446). */
 typedef struct okge_shard {
     int32_t ent_lo, ent_hi;
     int32_t cand_col0;
@@ -166,7 +170,16 @@ int okge_encode_queries(const okge_tables *t, const okge_shard *shard, const okg
 int okge_train_tiles(const okge_tables *t, const okge_shard *shard, const float *Q, int64_t ldq, int32_t B,
                      const okge_candidates *local_cand, const okge_positives *pos, int32_t loss_kind,
                      float label_smoothing, double normalizer, int32_t n_cand_global, int32_t flags,
-                     double *loss_out, float *dE, float *dQ, void *workspace, size_t workspace_bytes, void *stream);
+                     const float *row_lse, double *loss_out, float *dE, float *dQ, void *workspace,
+                     size_t workspace_bytes, void *stream);
+/* scores[b][j] = Q[b] . dropout(E_local[candidate j]) for the local candidates (evaluation / KL statistics) */
+int okge_score_queries(const okge_tables *t, const okge_shard *shard, const float *Q, int64_t ldq, int32_t B,
+                       const okge_candidates *local_cand, float *scores, int64_t ld_scores, void *stream);
+/* row_lse[b] = log sum_j exp(score[b][j]) over the local candidates, without materialising the scores
+ * (the log_softmax denominator of trainer.py:99-101, per shard) */
+int okge_row_logsumexp(const okge_tables *t, const okge_shard *shard, const float *Q, int64_t ldq, int32_t B,
+                       const okge_candidates *local_cand, float *row_lse, void *workspace, size_t workspace_bytes,
+                       void *stream);
 int okge_prefix_backward(const okge_tables *t, const okge_shard *shard, const okge_prefix_batch *batch,
                          const float *dQ, int64_t ldq, const float *ent_rows, float *dE, float *dR, void *stream);
 
@@ -207,6 +220,16 @@ int okge_filtered_ranks(const float *scores, int64_t ld_scores, int32_t B, int32
                         const int64_t *filt_ptr, const int32_t *filt_col,
                         const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, void *stream);
+/* The same rank rule with the candidate columns [col0, col0 + n_local) of every row held by this rank
+ * (scores: B x n_local; filter columns and group ids stay positions in the FULL candidate list):
+ * true_out[g] = max over the group's ids inside the local range (-inf if none)       -> all-reduce(max)
+ * counts[g]   = {#(scores' > true[g]), #(scores' == true[g])} over the local columns -> all-reduce(sum) */
+int okge_group_true_scores(const float *scores, int64_t ld_scores, int32_t B, int32_t col0, int32_t n_local,
+                           const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids, float *true_out,
+                           void *stream);
+int okge_rank_counts(const float *scores, int64_t ld_scores, int32_t B, int32_t col0, int32_t n_local,
+                     const int64_t *filt_ptr, const int32_t *filt_col, const int64_t *row_ptr,
+                     const float *true_scores, int64_t *counts, void *stream);
 
 /* ---- measurement ------------------------------------------------------------------------------------
  * When enabled, every kernel launch of the calls above is bracketed by HIP events on its stream.

@@ -27,7 +27,8 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 # every symbol include/okge.h declares
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
-           "okge_prefix_backward", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_prefix_backward", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
+           "okge_rank_counts", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -115,7 +116,19 @@ def lib():
     L.okge_train_tiles.restype = c_int32
     L.okge_train_tiles.argtypes = [POINTER(Tables), POINTER(Shard), c_void_p, c_int64, c_int32, POINTER(Candidates),
                                    POINTER(Positives), c_int32, c_float, c_double, c_int32, c_int32, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_size_t, c_void_p]
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    L.okge_score_queries.restype = c_int32
+    L.okge_score_queries.argtypes = [POINTER(Tables), POINTER(Shard), c_void_p, c_int64, c_int32, POINTER(Candidates),
+                                     c_void_p, c_int64, c_void_p]
+    L.okge_row_logsumexp.restype = c_int32
+    L.okge_row_logsumexp.argtypes = [POINTER(Tables), POINTER(Shard), c_void_p, c_int64, c_int32, POINTER(Candidates),
+                                     c_void_p, c_void_p, c_size_t, c_void_p]
+    L.okge_group_true_scores.restype = c_int32
+    L.okge_group_true_scores.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]
+    L.okge_rank_counts.restype = c_int32
+    L.okge_rank_counts.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]
     L.okge_prefix_backward.restype = c_int32
     L.okge_prefix_backward.argtypes = [POINTER(Tables), POINTER(Shard), POINTER(PrefixBatch), c_void_p, c_int64, c_void_p,
                                        c_void_p, c_void_p, c_void_p]

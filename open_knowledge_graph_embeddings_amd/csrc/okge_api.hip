@@ -194,7 +194,7 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
     a.E = c->table ? c->table : t->E;       // table the candidate rows are gathered from
     a.cand_ids = c->ids;
     a.cand_first = c->first_id;
-    a.Q = reinterpret_cast<const float *>(ws + g.off_Q);
+    a.Q = ws ? reinterpret_cast<const float *>(ws + g.off_Q) : nullptr;
     a.drop_c = to_dev(c->drop);
     a.d = g.d; a.KB = g.KB; a.LDK = g.LDK; a.N = g.N; a.B = g.B; a.Bpad = g.Bpad; a.ldq = g.ldq; a.ldg = g.ldg;
     a.b_per_block = g.b_per_block;
@@ -255,7 +255,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
                       int64_t ldq_ext, int32_t B, const okge_candidates *cand, const okge_positives *pos,
                       int32_t loss_kind, float label_smoothing, double normalizer, int32_t n_cand_global, int32_t flags,
                       double *loss_out, float *dE, float *dR, float *dq_out, float *scores, int64_t ld_scores,
-                      void *workspace, size_t workspace_bytes, void *stream)
+                      const float *row_lse_ext, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!pos || pos->nnz < 0 || (pos->nnz > 0 && (!pos->col || !pos->row)))
         return fail(OKGE_ERR_INVALID, "bad positives");
@@ -315,21 +315,24 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     if (loss_kind == OKGE_LOSS_KL) {
-        if (sh) return fail(OKGE_ERR_UNSUPPORTED, "the KL loss needs row statistics across shards: not implemented");
+        if (sh && !row_lse_ext)
+            return fail(OKGE_ERR_INVALID, "sharded KL loss: pass the all-shard row log-sum-exp (okge_row_logsumexp + exchange)");
         FusedArgs s = a;
         s.stats = reinterpret_cast<float *>(ws + g.off_stats);
         s.b_per_block = g.Bpad;
-        {
+        if (!row_lse_ext) {
             ScopedTimer tm("fused_tile_stats", st);
             e = g.KB <= 16 ? launch_fused(MODE_STATS, s, g.tiles, 1, st) : launch_fused32(MODE_STATS, s, g.ktiles, 1, st);
             if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
         }
         ScopedTimer tm("kl_row_stats", st);
         // the 64x64 cut emits one (max, sum-exp) per 64-candidate tile, the 32x32 cut one per 16-candidate block
-        e = launch_kl_row_stats(s.stats, g.KB <= 16 ? g.tiles : 2 * g.ktiles, g.B, g.Bpad, pos->row, pos->nnz,
-                                reinterpret_cast<float *>(ws + g.off_lse), reinterpret_cast<float *>(ws + g.off_ysum), st);
+        // (with an external log-sum-exp only the per-row label mass is computed here: 0 statistic tiles)
+        e = launch_kl_row_stats(s.stats, row_lse_ext ? 0 : (g.KB <= 16 ? g.tiles : 2 * g.ktiles), g.B, g.Bpad, pos->row,
+                                pos->nnz, reinterpret_cast<float *>(ws + g.off_lse),
+                                reinterpret_cast<float *>(ws + g.off_ysum), st);
         if (e != hipSuccess) return fail_hip(e, "kl_row_stats");
-        a.row_lse = reinterpret_cast<const float *>(ws + g.off_lse);
+        a.row_lse = row_lse_ext ? row_lse_ext : reinterpret_cast<const float *>(ws + g.off_lse);
         a.row_ysum = reinterpret_cast<const float *>(ws + g.off_ysum);
     }
 #ifdef OKGE_STAMPS
@@ -388,7 +391,7 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     if (int rc = check_common(t, batch, cand)) return rc;
     if (!(flags & OKGE_TRAIN_LOSS_ONLY) && !dR) return fail(OKGE_ERR_INVALID, "null output");
     return train_core(t, nullptr, batch, nullptr, 0, batch->n_po + batch->n_sp, cand, pos, loss_kind, label_smoothing,
-                      normalizer, cand->n, flags, loss_out, dE, dR, nullptr, scores, ld_scores, workspace,
+                      normalizer, cand->n, flags, loss_out, dE, dR, nullptr, scores, ld_scores, nullptr, workspace,
                       workspace_bytes, stream);
 }
 
@@ -430,8 +433,8 @@ int okge_encode_queries(const okge_tables *t, const okge_shard *sh, const okge_p
 
 int okge_train_tiles(const okge_tables *t, const okge_shard *sh, const float *Q, int64_t ldq, int32_t B,
                      const okge_candidates *cand, const okge_positives *pos, int32_t loss_kind, float label_smoothing,
-                     double normalizer, int32_t n_cand_global, int32_t flags, double *loss_out, float *dE, float *dQ,
-                     void *workspace, size_t workspace_bytes, void *stream)
+                     double normalizer, int32_t n_cand_global, int32_t flags, const float *row_lse, double *loss_out,
+                     float *dE, float *dQ, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!t || !cand || !t->E || t->d <= 0 || t->n_ent <= 0) return fail(OKGE_ERR_INVALID, "bad tables");
     if (t->d > 512) return fail(OKGE_ERR_UNSUPPORTED, "slot sizes above 512 are not supported by the tile kernels");
@@ -440,7 +443,73 @@ int okge_train_tiles(const okge_tables *t, const okge_shard *sh, const float *Q,
     if (!cand->ids && (cand->first_id < 0 || (int64_t)cand->first_id + cand->n > t->n_ent))
         return fail(OKGE_ERR_INVALID, "candidate range outside the local entity table");
     return train_core(t, sh, nullptr, Q, ldq, B, cand, pos, loss_kind, label_smoothing, normalizer, n_cand_global,
-                      flags, loss_out, dE, nullptr, dQ, nullptr, 0, workspace, workspace_bytes, stream);
+                      flags, loss_out, dE, nullptr, dQ, nullptr, 0, row_lse, workspace, workspace_bytes, stream);
+}
+
+static int check_query_call(const okge_tables *t, const okge_shard *sh, const float *Q, int64_t ldq, int32_t B,
+                            const okge_candidates *cand)
+{
+    if (!t || !cand || !t->E || t->d <= 0 || t->n_ent <= 0) return fail(OKGE_ERR_INVALID, "bad tables");
+    if (t->d > 512) return fail(OKGE_ERR_UNSUPPORTED, "slot sizes above 512 are not supported by the tile kernels");
+    if (int rc = check_shard(t, sh)) return rc;
+    if (!Q || B <= 0 || cand->n <= 0 || ldq != okge_query_ld(t->d))
+        return fail(OKGE_ERR_INVALID, "bad query block / candidates");
+    if (cand->table) return fail(OKGE_ERR_INVALID, "sharded calls take candidates from the local entity table");
+    if (!cand->ids && (cand->first_id < 0 || (int64_t)cand->first_id + cand->n > t->n_ent))
+        return fail(OKGE_ERR_INVALID, "candidate range outside the local entity table");
+    return OKGE_OK;
+}
+
+int okge_score_queries(const okge_tables *t, const okge_shard *sh, const float *Q, int64_t ldq, int32_t B,
+                       const okge_candidates *cand, float *scores, int64_t ld_scores, void *stream)
+{
+    if (int rc = check_query_call(t, sh, Q, ldq, B, cand)) return rc;
+    if (!scores || ld_scores < cand->n) return fail(OKGE_ERR_INVALID, "bad scores buffer");
+    Geometry g;
+    make_geometry(B, cand->n, t->d, g);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    FusedArgs a;
+    fill_fused_common(a, g, t, cand, nullptr);
+    a.Q = Q;
+    a.cand_col0 = sh->cand_col0;
+    a.X = scores;
+    a.ldx = ld_scores;
+    a.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
+    a.b_per_block = g.Bpad;
+    ScopedTimer tm("fused_tile_score", st);
+    hipError_t e = g.KB <= 16 ? launch_fused(MODE_SCORE, a, g.tiles, 1, st) : launch_fused32(MODE_SCORE, a, g.ktiles, 1, st);
+    if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
+    return OKGE_OK;
+}
+
+int okge_row_logsumexp(const okge_tables *t, const okge_shard *sh, const float *Q, int64_t ldq, int32_t B,
+                       const okge_candidates *cand, float *row_lse, void *workspace, size_t workspace_bytes,
+                       void *stream)
+{
+    if (int rc = check_query_call(t, sh, Q, ldq, B, cand)) return rc;
+    if (!row_lse) return fail(OKGE_ERR_INVALID, "null output");
+    Geometry g;
+    make_geometry(B, cand->n, t->d, g);
+    if (!workspace || workspace_bytes < g.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    FusedArgs a;
+    fill_fused_common(a, g, t, cand, ws);
+    a.Q = Q;
+    a.cand_col0 = sh->cand_col0;
+    a.stats = reinterpret_cast<float *>(ws + g.off_stats);
+    a.b_per_block = g.Bpad;
+    hipError_t e;
+    {
+        ScopedTimer tm("fused_tile_stats", st);
+        e = g.KB <= 16 ? launch_fused(MODE_STATS, a, g.tiles, 1, st) : launch_fused32(MODE_STATS, a, g.ktiles, 1, st);
+        if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
+    }
+    ScopedTimer tm("kl_row_stats", st);
+    e = launch_kl_row_stats(a.stats, g.KB <= 16 ? g.tiles : 2 * g.ktiles, g.B, g.Bpad, nullptr, 0, row_lse,
+                            reinterpret_cast<float *>(ws + g.off_ysum), st);
+    if (e != hipSuccess) return fail_hip(e, "kl_row_stats");
+    return OKGE_OK;
 }
 
 int okge_prefix_backward(const okge_tables *t, const okge_shard *sh, const okge_prefix_batch *batch, const float *dQ,
@@ -524,8 +593,38 @@ int okge_filtered_ranks(const float *scores, int64_t ld_scores, int32_t B, int32
         return fail(OKGE_ERR_INVALID, "bad rank arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ScopedTimer tm("filtered_ranks", st);
-    hipError_t e = launch_ranks(scores, ld_scores, B, N, filt_ptr, filt_col, row_ptr, grp_ptr, ids, ranks, st);
+    hipError_t e = launch_ranks(scores, ld_scores, B, N, filt_ptr, filt_col, row_ptr, grp_ptr, ids, ranks, 0, nullptr,
+                                nullptr, nullptr, st);
     if (e != hipSuccess) return fail_hip(e, "ranks");
+    return OKGE_OK;
+}
+
+int okge_group_true_scores(const float *scores, int64_t ld_scores, int32_t B, int32_t col0, int32_t n_local,
+                           const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids, float *true_out,
+                           void *stream)
+{
+    if (!scores || !row_ptr || !grp_ptr || !ids || !true_out || B <= 0 || n_local <= 0 || col0 < 0 || ld_scores < n_local)
+        return fail(OKGE_ERR_INVALID, "bad rank arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("group_true_scores", st);
+    hipError_t e = launch_ranks(scores, ld_scores, B, n_local, row_ptr /* unused */, nullptr, row_ptr, grp_ptr, ids, nullptr,
+                                col0, nullptr, true_out, nullptr, st);
+    if (e != hipSuccess) return fail_hip(e, "ranks<true>");
+    return OKGE_OK;
+}
+
+int okge_rank_counts(const float *scores, int64_t ld_scores, int32_t B, int32_t col0, int32_t n_local,
+                     const int64_t *filt_ptr, const int32_t *filt_col, const int64_t *row_ptr, const float *true_scores,
+                     int64_t *counts, void *stream)
+{
+    if (!scores || !filt_ptr || !row_ptr || !true_scores || !counts || B <= 0 || n_local <= 0 || col0 < 0 ||
+        ld_scores < n_local)
+        return fail(OKGE_ERR_INVALID, "bad rank arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("rank_counts", st);
+    hipError_t e = launch_ranks(scores, ld_scores, B, n_local, filt_ptr, filt_col, row_ptr, nullptr, nullptr, nullptr, col0,
+                                true_scores, nullptr, counts, st);
+    if (e != hipSuccess) return fail_hip(e, "ranks<counts>");
     return OKGE_OK;
 }
 

@@ -413,7 +413,7 @@ constexpr int RANK_GROUPS = 8;
 // on the compares, and most rows have one or two groups.
 template <int NG>
 __device__ __forceinline__ void rank_sweep(const float *__restrict__ row, int64_t ld_is_vec, int N,
-                                           const int32_t *__restrict__ filt_col, int64_t f_lo, int64_t f_hi,
+                                           const int32_t *__restrict__ filt_col, int64_t f_lo, int64_t f_hi, int col0,
                                            const float *tv, int tid, int (&gt)[RANK_GROUPS], int (&eq)[RANK_GROUPS])
 {
     float t[NG];
@@ -443,7 +443,9 @@ __device__ __forceinline__ void rank_sweep(const float *__restrict__ row, int64_
     }
     // filtered positions count as -1e8 instead of their score (dataset.py:441)
     for (int64_t f = f_lo + tid; f < f_hi; f += 256) {
-        const float x = row[filt_col[f]];
+        const int col = filt_col[f] - col0;                     // a shard only sees its own candidate columns
+        if (col < 0 || col >= N) continue;
+        const float x = row[col];
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             g[j] += (-1e8f > t[j]) - (x > t[j]);
@@ -459,8 +461,14 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
                                                     const int32_t *__restrict__ filt_col,
                                                     const int64_t *__restrict__ row_ptr,
                                                     const int64_t *__restrict__ grp_ptr, const int32_t *__restrict__ ids,
-                                                    int64_t *__restrict__ ranks)
+                                                    int64_t *__restrict__ ranks, int col0,
+                                                    const float *__restrict__ true_in, float *__restrict__ true_out,
+                                                    int64_t *__restrict__ counts_out)
 {
+    // Whole candidate list (col0 = 0, true_in = true_out = counts_out = null): ranks.
+    // Candidate-sharded evaluation runs it twice around two tiny all-reduces:
+    //   true_out   : the shard's maximum over each group's ids that fall in [col0, col0 + N)   -> all-reduce(max)
+    //   true_in    : global true scores in, counts_out[g] = {#greater, #equal} of this shard   -> all-reduce(sum)
     __shared__ float tv[RANK_GROUPS];
     __shared__ int cnt[4][2 * RANK_GROUPS];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -473,17 +481,26 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
         if (tid < RANK_GROUPS) {
             float t = __builtin_nanf("");                       // unused slots never compare true
             if (tid < ng) {
-                t = -INFINITY;
-                for (int64_t j = grp_ptr[g0 + tid]; j < grp_ptr[g0 + tid + 1]; ++j) t = fmaxf(t, row[ids[j]]);
+                if (true_in) {
+                    t = true_in[g0 + tid];
+                } else {
+                    t = -INFINITY;
+                    for (int64_t j = grp_ptr[g0 + tid]; j < grp_ptr[g0 + tid + 1]; ++j) {
+                        const int col = ids[j] - col0;
+                        if (col >= 0 && col < N) t = fmaxf(t, row[col]);
+                    }
+                    if (true_out) true_out[g0 + tid] = t;
+                }
             }
             tv[tid] = t;
         }
+        if (true_out) continue;                                 // uniform: phase 1 of the sharded evaluation
         __syncthreads();
         int gt[RANK_GROUPS], eq[RANK_GROUPS];
-        if (ng == 1)      rank_sweep<1>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
-        else if (ng == 2) rank_sweep<2>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
-        else if (ng <= 4) rank_sweep<4>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
-        else              rank_sweep<8>(row, vec, N, filt_col, f_lo, f_hi, tv, tid, gt, eq);
+        if (ng == 1)      rank_sweep<1>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        else if (ng == 2) rank_sweep<2>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        else if (ng <= 4) rank_sweep<4>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        else              rank_sweep<8>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
 #pragma unroll
         for (int j = 0; j < RANK_GROUPS; ++j) {
             const int a = wave_sum(gt[j]), e = wave_sum(eq[j]);
@@ -493,7 +510,12 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
         if (tid < ng) {
             const int64_t a = (int64_t)cnt[0][2 * tid] + cnt[1][2 * tid] + cnt[2][2 * tid] + cnt[3][2 * tid];
             const int64_t e = (int64_t)cnt[0][2 * tid + 1] + cnt[1][2 * tid + 1] + cnt[2][2 * tid + 1] + cnt[3][2 * tid + 1];
-            ranks[g0 + tid] = a + e / 2;
+            if (counts_out) {
+                counts_out[2 * (g0 + tid)] = a;
+                counts_out[2 * (g0 + tid) + 1] = e;
+            } else {
+                ranks[g0 + tid] = a + e / 2;
+            }
         }
         __syncthreads();
     }
@@ -551,7 +573,8 @@ hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, c
     hipError_t e = hipMemsetAsync(row_ysum, 0, sizeof(float) * Bpad, st);
     if (e != hipSuccess) return e;
     if (nnz > 0) hipLaunchKernelGGL(kl_count_pos_kernel, dim3((nnz + 255) / 256), dim3(256), 0, st, pos_row, nnz, row_ysum);
-    hipLaunchKernelGGL(kl_row_lse_kernel, dim3((B + 255) / 256), dim3(256), 0, st, stats, tiles, B, Bpad, row_lse);
+    if (tiles > 0)
+        hipLaunchKernelGGL(kl_row_lse_kernel, dim3((B + 255) / 256), dim3(256), 0, st, stats, tiles, B, Bpad, row_lse);
     return hipGetLastError();
 }
 
@@ -594,11 +617,12 @@ hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p
 
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
-                        int64_t *ranks, hipStream_t st)
+                        int64_t *ranks, int col0, const float *true_in, float *true_out, int64_t *counts_out,
+                        hipStream_t st)
 {
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(ranks_kernel, dim3(B), dim3(256), 0, st, scores, ld, N, filt_ptr, filt_col, row_ptr, grp_ptr,
-                       ids, ranks);
+                       ids, ranks, col0, true_in, true_out, counts_out);
     return hipGetLastError();
 }
 

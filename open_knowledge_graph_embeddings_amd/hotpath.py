@@ -225,8 +225,9 @@ class HotPath:
         return out
 
     def train_tiles(self, E_local, R, scorer, Q, batch: PrefixBatch, shard: Shard, dE, dQ, n_cand_global, loss="bce",
-                    label_smoothing=0.0, normalizer=None, loss_out=None, grads_zero=False):
-        """Local candidates only: batch.cand_first / n_cand are LOCAL row indices, batch.pos_col GLOBAL columns."""
+                    label_smoothing=0.0, normalizer=None, loss_out=None, grads_zero=False, row_lse=None):
+        """Local candidates only: batch.cand_first / n_cand are LOCAL row indices, batch.pos_col GLOBAL columns.
+        KL loss: `row_lse` = log-sum-exp of every row's scores over ALL shards' candidates."""
         pb, c, keep = self._batch(batch)
         t = self._tables(E_local, R, scorer)
         B, n = batch.B, c.n
@@ -242,10 +243,36 @@ class HotPath:
         N.check(self.lib.okge_train_tiles(
             ctypes.byref(t), ctypes.byref(sh), Q.data_ptr(), Q.stride(0), B, ctypes.byref(c), ctypes.byref(pos),
             N.LOSSES[loss] if isinstance(loss, str) else int(loss), float(label_smoothing), float(normalizer),
-            int(n_cand_global), N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0, loss_out.data_ptr(), dE.data_ptr(),
-            dQ.data_ptr(), ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_tiles")
+            int(n_cand_global), N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0, _ptr(row_lse), loss_out.data_ptr(),
+            dE.data_ptr(), dQ.data_ptr(), ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_tiles")
         del keep, prow, pcol
         return loss_out
+
+    def score_queries(self, E_local, R, scorer, Q, B, batch: PrefixBatch, shard: Shard, out=None):
+        """(B, n_local) scores of precomputed query rows against the local candidates."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E_local, R, scorer)
+        if out is None:
+            out = torch.empty((B, (c.n + 3) // 4 * 4), dtype=torch.float32, device=self.device)[:, :c.n]
+        sh = shard.c()
+        N.check(self.lib.okge_score_queries(ctypes.byref(t), ctypes.byref(sh), Q.data_ptr(), Q.stride(0), B,
+                                            ctypes.byref(c), out.data_ptr(), out.stride(0), self._stream()),
+                "okge_score_queries")
+        del keep
+        return out
+
+    def row_logsumexp(self, E_local, R, scorer, Q, B, batch: PrefixBatch, shard: Shard):
+        """(B,) log-sum-exp of each query row's scores over the local candidates (scores are not materialised)."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E_local, R, scorer)
+        ws = self.workspace(B, c.n, t.d)
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        sh = shard.c()
+        N.check(self.lib.okge_row_logsumexp(ctypes.byref(t), ctypes.byref(sh), Q.data_ptr(), Q.stride(0), B,
+                                            ctypes.byref(c), out.data_ptr(), ws.data_ptr(), self._ws_bytes,
+                                            self._stream()), "okge_row_logsumexp")
+        del keep
+        return out
 
     def prefix_backward(self, E_local, R, scorer, batch: PrefixBatch, shard: Shard, dQ, ent_rows, dE, dR):
         pb, c, keep = self._batch(batch)
@@ -295,6 +322,24 @@ class HotPath:
                                              _ptr(filt_col), row_ptr.data_ptr(), grp_ptr.data_ptr(), ids.data_ptr(),
                                              ranks.data_ptr(), self._stream()), "okge_filtered_ranks")
         return ranks
+
+    def group_true_scores(self, scores, col0, row_ptr, grp_ptr, ids):
+        """float32 per answer group: max score over the group's ids inside columns [col0, col0 + n_local)."""
+        out = torch.empty(int(grp_ptr.numel()) - 1, dtype=torch.float32, device=self.device)
+        B, n = scores.shape
+        N.check(self.lib.okge_group_true_scores(scores.data_ptr(), scores.stride(0), B, int(col0), n, row_ptr.data_ptr(),
+                                                grp_ptr.data_ptr(), ids.data_ptr(), out.data_ptr(), self._stream()),
+                "okge_group_true_scores")
+        return out
+
+    def rank_counts(self, scores, col0, filt_ptr, filt_col, row_ptr, true_scores):
+        """int64 (n_groups, 2): {#greater, #equal} over the local candidate columns."""
+        out = torch.empty((int(true_scores.numel()), 2), dtype=torch.int64, device=self.device)
+        B, n = scores.shape
+        N.check(self.lib.okge_rank_counts(scores.data_ptr(), scores.stride(0), B, int(col0), n, filt_ptr.data_ptr(),
+                                          _ptr(filt_col), row_ptr.data_ptr(), true_scores.data_ptr(), out.data_ptr(),
+                                          self._stream()), "okge_rank_counts")
+        return out
 
     # -- measurement --------------------------------------------------------------------------------
     def timing(self, on):

@@ -9,6 +9,10 @@ loss is separable, so one step needs exactly two small exchanges:
     all-reduce(sum)  [2, B, d]  folded queries + masked prefix entity rows   (each row is non-zero on its owner)
     all-reduce(sum)  [B, d]     partial query gradients dQ                    (+ the scalar loss, off the critical path)
 
+The KL loss (log_softmax over ALL candidates, trainer.py:99-101) adds one: all-gather of the [B] per-shard row
+log-sum-exp.  Evaluation (`ShardedEvaluator`) exchanges the true-answer scores (all-reduce max) and the integer
+{#greater, #equal} counts (all-reduce sum); exact ranks need counts, not a per-shard top-k.
+
 Entity rows, their dense gradients and Adagrad accumulators never leave their rank; the (small) relation table is
 replicated and its gradient is formed identically everywhere from the exchanged entity rows.
 
@@ -39,8 +43,8 @@ class ShardedTrainStep:
         self.ent_lo, self.ent_hi = shard_range(n_ent, self.world, self.rank)
         if E_local.shape[0] != self.ent_hi - self.ent_lo:
             raise ValueError("E_local must hold exactly this rank's rows")
-        if loss != "bce":
-            raise NotImplementedError("sharded training implements the BCE loss (KL needs cross-shard row statistics)")
+        if loss not in ("bce", "kl"):
+            raise NotImplementedError(f"loss {loss!r}")
         self.E, self.R, self.scorer = E_local, R, scorer
         self.n_ent, self.min_ent = n_ent, min_entities_size
         self.lr, self.weight_decay, self.eps = lr, weight_decay, eps
@@ -81,9 +85,16 @@ class ShardedTrainStep:
                               pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=self.cand_first_local,
                               n_cand=self.n_cand_local, drop_cand=batch.drop_cand)
         dq = torch.empty_like(qe[0])
+        row_lse = None
+        if self.loss == "kl":
+            lse = eng.row_logsumexp(self.E, self.R, self.scorer, qe[0], batch.B, local, self.shard)
+            every = torch.empty(self.world * batch.B, dtype=lse.dtype, device=lse.device)
+            dist.all_gather_into_tensor(every, lse, group=self.group)
+            row_lse = torch.logsumexp(every.view(self.world, batch.B), dim=0).contiguous()
         eng.train_tiles(self.E, self.R, self.scorer, qe[0], local, self.shard, self.dE, dq, self.n_cand_global,
                         loss=self.loss, label_smoothing=self.label_smoothing,
-                        normalizer=float(batch.B) * float(self.n_cand_global), loss_out=self.loss_out, grads_zero=True)
+                        normalizer=float(batch.B) * float(self.n_cand_global), loss_out=self.loss_out, grads_zero=True,
+                        row_lse=row_lse)
         dist.all_reduce(dq, group=self.group)
         loss_work = dist.all_reduce(self.loss_out, group=self.group, async_op=True)
         # 3. chain rule: entity rows by their owner, relation rows everywhere (identical)
@@ -93,3 +104,42 @@ class ShardedTrainStep:
                      zero_grad=True)
         loss_work.wait()
         return self.loss_out
+
+
+class ShardedEvaluator:
+    """Filtered ranks with the candidates sharded like the entity table (compute_metrics' rank rule,
+    dataset.py:423-446; exchange plan of SURVEY.md section 8e)."""
+
+    def __init__(self, E_local, R, scorer, n_ent, min_entities_size=2, engine=None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.ent_lo, self.ent_hi = shard_range(n_ent, self.world, self.rank)
+        if E_local.shape[0] != self.ent_hi - self.ent_lo:
+            raise ValueError("E_local must hold exactly this rank's rows")
+        self.E, self.R, self.scorer = E_local, R, scorer
+        self.engine = engine or H.HotPath(E_local.device)
+        c_lo = max(self.ent_lo, min_entities_size)
+        self.cand_first_local = c_lo - self.ent_lo
+        self.n_cand_local = max(0, self.ent_hi - c_lo)
+        self.col0 = c_lo - min_entities_size
+        self.shard = H.Shard(self.ent_lo, self.ent_hi, self.col0)
+
+    def local_scores(self, batch: H.PrefixBatch):
+        eng = self.engine
+        qe = eng.encode_queries(self.E, self.R, self.scorer, batch, self.shard)
+        dist.all_reduce(qe, group=self.group)
+        local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
+                              cand_first=self.cand_first_local, n_cand=self.n_cand_local)
+        return eng.score_queries(self.E, self.R, self.scorer, qe[0], batch.B, local, self.shard)
+
+    def ranks(self, batch: H.PrefixBatch, filt_ptr, filt_col, row_ptr, grp_ptr, ids):
+        """int64 rank per answer group, identical on every rank.  Index arrays are global (positions in the full
+        candidate list) and identical on every rank."""
+        eng = self.engine
+        x = self.local_scores(batch)
+        true = eng.group_true_scores(x, self.col0, row_ptr, grp_ptr, ids)
+        dist.all_reduce(true, op=dist.ReduceOp.MAX, group=self.group)
+        counts = eng.rank_counts(x, self.col0, filt_ptr, filt_col, row_ptr, true)
+        dist.all_reduce(counts, group=self.group)
+        return counts[:, 0] + counts[:, 1] // 2

@@ -58,25 +58,68 @@ class OracleShardEngine:
                 buf[1, b, :d] = e
         return torch.from_numpy(buf)
 
-    def train_tiles(self, E_local, R, scorer, Q, batch, shard, dE, dQ, n_cand_global, loss="bce", label_smoothing=0.0,
-                    normalizer=None, loss_out=None, grads_zero=False):
+    def _local_scores(self, E_local, Q, B, batch, shard):
         E = _np(E_local)
         d = E.shape[1]
-        B, n = batch.B, batch.n_cand
-        lo = batch.cand_first
+        n, lo = batch.n_cand, batch.cand_first
         keep = _keep(batch.drop_cand, n, d, row_keys=np.arange(n, dtype=np.uint32) + np.uint32(shard.cand_col0))
         C = E[lo:lo + n]
         if keep is not None:
             C = C * (keep.astype(np.float32) / np.float32(1 - batch.drop_cand.p))
         q = _np(Q)[:B, :d]
-        X = q @ C.T
+        return q, C, keep, (q @ C.T).astype(np.float32)
+
+    def score_queries(self, E_local, R, scorer, Q, B, batch, shard, out=None):
+        return torch.from_numpy(self._local_scores(E_local, Q, B, batch, shard)[3])
+
+    def row_logsumexp(self, E_local, R, scorer, Q, B, batch, shard):
+        X = self._local_scores(E_local, Q, B, batch, shard)[3].astype(np.float64)
+        m = X.max(axis=1)
+        return torch.from_numpy((m + np.log(np.exp(X - m[:, None]).sum(axis=1))).astype(np.float32))
+
+    def group_true_scores(self, scores, col0, row_ptr, grp_ptr, ids):
+        x, rp, gp, idn = _np(scores), _np(row_ptr), _np(grp_ptr), _np(ids)
+        out = np.full(len(gp) - 1, -np.inf, np.float32)
+        for b in range(x.shape[0]):
+            for g in range(rp[b], rp[b + 1]):
+                j = idn[gp[g]:gp[g + 1]].astype(np.int64) - col0
+                j = j[(j >= 0) & (j < x.shape[1])]
+                if len(j):
+                    out[g] = x[b, j].max()
+        return torch.from_numpy(out)
+
+    def rank_counts(self, scores, col0, filt_ptr, filt_col, row_ptr, true_scores):
+        x, fp, fc, rp, tv = _np(scores).copy(), _np(filt_ptr), _np(filt_col), _np(row_ptr), _np(true_scores)
+        out = np.zeros((len(tv), 2), np.int64)
+        for b in range(x.shape[0]):
+            j = fc[fp[b]:fp[b + 1]].astype(np.int64) - col0
+            j = j[(j >= 0) & (j < x.shape[1])]
+            x[b, j] = np.float32(-1e8)
+            for g in range(rp[b], rp[b + 1]):
+                out[g] = ((x[b] > tv[g]).sum(), (x[b] == tv[g]).sum())
+        return torch.from_numpy(out)
+
+    def train_tiles(self, E_local, R, scorer, Q, batch, shard, dE, dQ, n_cand_global, loss="bce", label_smoothing=0.0,
+                    normalizer=None, loss_out=None, grads_zero=False, row_lse=None):
+        d = E_local.shape[1]
+        B, n = batch.B, batch.n_cand
+        lo = batch.cand_first
+        q, C, keep, X = self._local_scores(E_local, Q, B, batch, shard)
         y = np.zeros((B, n), np.float32)
         pr, pc = _np(batch.pos_row), _np(batch.pos_col) - shard.cand_col0
         sel = (pc >= 0) & (pc < n)
         y[pr[sel], pc[sel]] = 1
-        if label_smoothing > 0:
-            y = (y + np.float32(1.0 / n_cand_global)) * np.float32(1 - label_smoothing)
-        lsum, g = ko.loss_and_dscore(X, y, ko.LOSS_BCE, 0.0)
+        if loss == "kl":
+            # softmax over ALL shards' candidates through the exchanged row log-sum-exp (trainer.py:99-101,106);
+            # labels are {0,1}, so xlogy(y,y) = 0
+            lsm = X - _np(row_lse)[:B, None]
+            ysum = np.bincount(pr, minlength=B).astype(np.float32)[:, None]      # label mass over all shards
+            lsum = float((-y * lsm).sum(dtype=np.float64))
+            g = np.exp(lsm) * ysum - y
+        else:
+            if label_smoothing > 0:
+                y = (y + np.float32(1.0 / n_cand_global)) * np.float32(1 - label_smoothing)
+            lsum, g = ko.loss_and_dscore(X, y, ko.LOSS_BCE, 0.0)
         G = (g / np.float32(normalizer)).astype(np.float32)
         dC = G.T @ q
         if keep is not None:

@@ -41,7 +41,38 @@ def tables():
     return (rng.standard_normal((N_ENT, D)) * 0.3).astype(np.float32), (rng.standard_normal((N_REL, D)) * 0.3).astype(np.float32)
 
 
-def oracle_reference(nsteps, p=P_DROP):
+def eval_problem(seed=5):
+    """answer groups (some with several mentions), all-splits filter incl. the answers; global candidate columns"""
+    rng = np.random.default_rng(seed)
+    b = problem(seed)
+    B, nc = N_PO + N_SP, N_ENT - 2
+    row_ptr, grp_ptr, ids, filt_ptr, filt_col = [0], [0], [], [0], []
+    for r in range(B):
+        for _ in range(int(rng.integers(1, 4))):
+            ids += rng.choice(nc, size=int(rng.integers(1, 4)), replace=False).tolist()
+            grp_ptr.append(len(ids))
+        row_ptr.append(len(grp_ptr) - 1)
+        mine = ids[grp_ptr[row_ptr[r]]:]
+        filt_col += sorted(set(mine) | set(rng.choice(nc, size=4, replace=False).tolist()))
+        filt_ptr.append(len(filt_col))
+    b.update(row_ptr=np.asarray(row_ptr, np.int64), grp_ptr=np.asarray(grp_ptr, np.int64), ids=np.asarray(ids, np.int32),
+             filt_ptr=np.asarray(filt_ptr, np.int64), filt_col=np.asarray(filt_col, np.int32))
+    return b
+
+
+def oracle_ranks(b):
+    E, R = tables()
+    kind, C = ko.KIND_NAMES[SCORER], None
+    C = E[2:]
+    x = np.concatenate([ko.score_prefix(kind, ko.DIR_PO, E[b["po_obj"]], R[b["po_rel"]], C),
+                        ko.score_prefix(kind, ko.DIR_SP, E[b["sp_subj"]], R[b["sp_rel"]], C)])
+    filt = np.zeros(x.shape, bool)
+    for r in range(x.shape[0]):
+        filt[r, b["filt_col"][b["filt_ptr"][r]:b["filt_ptr"][r + 1]]] = True
+    return ko.filtered_ranks(x, filt, b["row_ptr"], b["grp_ptr"], b["ids"])
+
+
+def oracle_reference(nsteps, p=P_DROP, loss=ko.LOSS_BCE):
     from open_knowledge_graph_embeddings_amd import hotpath as H
     E, R = tables()
     sE, sR = np.zeros_like(E), np.zeros_like(R)
@@ -54,7 +85,7 @@ def oracle_reference(nsteps, p=P_DROP):
                       keep_po_ent=ko.dropout_keep_mask(SEED, H.STREAM_PO_ENT, step, N_PO, D, p),
                       keep_sp_ent=ko.dropout_keep_mask(SEED, H.STREAM_SP_ENT, step, N_SP, D, p))
         out = ko.step_forward_backward(ko.KIND_NAMES[SCORER], E, R, (b["po_rel"], b["po_obj"]), (b["sp_subj"], b["sp_rel"]),
-                                       np.arange(2, N_ENT), b["labels"], **kw)
+                                       np.arange(2, N_ENT), b["labels"], loss_kind=loss, **kw)
         ko.adagrad_step(E, out["dE"], sE, LR)
         ko.adagrad_step(R, out["dR"], sR, LR)
         losses.append(out["loss"])
@@ -69,35 +100,46 @@ def to_batch(b, dev):
 
 
 # ------------------------------------------------------------------------------------------- CPU, gloo, 2 ranks
-def _worker(rank, world, port, outdir, nsteps):
+def _worker(rank, world, port, outdir, nsteps, loss):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep, shard_range
+    from open_knowledge_graph_embeddings_amd.sharded import ShardedEvaluator, ShardedTrainStep, shard_range
     from shard_engine_cpu import OracleShardEngine
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     E, R = tables()
     lo, hi = shard_range(N_ENT, world, rank)
+    # evaluation on the initial tables: ranks must come out identical on every rank
+    ev = ShardedEvaluator(torch.from_numpy(E[lo:hi].copy()), torch.from_numpy(R.copy()), SCORER, N_ENT,
+                          engine=OracleShardEngine())
+    eb = eval_problem()
+    t = torch.from_numpy
+    ranks = ev.ranks(to_batch(eb, "cpu"), t(eb["filt_ptr"]), t(eb["filt_col"]), t(eb["row_ptr"]), t(eb["grp_ptr"]),
+                     t(eb["ids"]))
     st = ShardedTrainStep(torch.from_numpy(E[lo:hi].copy()), torch.from_numpy(R.copy()), SCORER, N_ENT, lr=LR,
-                          input_dropout=P_DROP, seed=SEED, engine=OracleShardEngine())
+                          input_dropout=P_DROP, seed=SEED, engine=OracleShardEngine(), loss=loss)
     losses = []
     for step in range(1, nsteps + 1):
         losses.append(float(st.step(to_batch(problem(step), "cpu"))[0]))
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"), E=st.E.numpy(), R=st.R.numpy(), lo=lo, hi=hi, losses=np.asarray(losses))
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), E=st.E.numpy(), R=st.R.numpy(), lo=lo, hi=hi,
+             losses=np.asarray(losses), ranks=ranks.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_exchange_protocol_gloo(world):
+@pytest.mark.parametrize("world,loss", [(2, "bce"), (3, "bce"), (2, "kl")])
+def test_sharded_exchange_protocol_gloo(world, loss):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     nsteps = 2
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker, args=(world, port, outdir, nsteps), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, outdir, nsteps, loss), nprocs=world, join=True)
         parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
-    E_ref, R_ref, losses_ref = oracle_reference(nsteps)
+    E_ref, R_ref, losses_ref = oracle_reference(nsteps, loss=ko.LOSS_KL if loss == "kl" else ko.LOSS_BCE)
+    ranks_ref = oracle_ranks(eval_problem())
+    for p in parts:                                       # sharded evaluation: exact integer ranks on every rank
+        np.testing.assert_array_equal(p["ranks"], ranks_ref)
     E = np.concatenate([p["E"] for p in parts])
     assert [int(p["lo"]) for p in parts] == sorted(int(p["lo"]) for p in parts) and E.shape == E_ref.shape
     close = np.isclose(E, E_ref, rtol=2e-4, atol=2e-5)
@@ -117,8 +159,8 @@ def test_shard_ranges_cover_table():
 
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_three_phase_abi_emulated_shards(world, okge_lib):
+@pytest.mark.parametrize("world,loss", [(2, "bce"), (3, "bce"), (2, "kl"), (3, "kl")])
+def test_three_phase_abi_emulated_shards(world, loss, okge_lib):
     """One device plays every rank in turn; the all-reduces are plain sums of the per-rank buffers."""
     from open_knowledge_graph_embeddings_amd import hotpath as H
     from open_knowledge_graph_embeddings_amd.sharded import shard_range
@@ -130,7 +172,8 @@ def test_three_phase_abi_emulated_shards(world, okge_lib):
               keep_po_ent=ko.dropout_keep_mask(SEED, H.STREAM_PO_ENT, step, N_PO, D, p),
               keep_sp_ent=ko.dropout_keep_mask(SEED, H.STREAM_SP_ENT, step, N_SP, D, p))
     ref = ko.step_forward_backward(ko.KIND_NAMES[SCORER], E, R, (b["po_rel"], b["po_obj"]), (b["sp_subj"], b["sp_rel"]),
-                                   np.arange(2, N_ENT), b["labels"], **kw)
+                                   np.arange(2, N_ENT), b["labels"],
+                                   loss_kind=ko.LOSS_KL if loss == "kl" else ko.LOSS_BCE, **kw)
     batch = to_batch(b, "cuda:0")
     batch.drop_cand = H.DropoutSpec(p, SEED, H.STREAM_CAND, step)
     batch.drop_po_ent = H.DropoutSpec(p, SEED, H.STREAM_PO_ENT, step)
@@ -144,14 +187,25 @@ def test_three_phase_abi_emulated_shards(world, okge_lib):
         Es.append(torch.from_numpy(E[lo:hi].copy()).cuda())
     qe = sum(hp.encode_queries(Es[r], Rt, SCORER, batch, shards[r][0]) for r in range(world))     # "all-reduce"
     dEs, dqs, losses = [], [], []
+
+    def local_batch(r):
+        return H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
+                             pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=shards[r][1], n_cand=shards[r][2],
+                             drop_cand=batch.drop_cand)
+
+    row_lse = None
+    if loss == "kl":                                                 # "all-gather" + log-sum-exp over ranks
+        row_lse = torch.logsumexp(torch.stack([hp.row_logsumexp(Es[r], Rt, SCORER, qe[0], batch.B, local_batch(r),
+                                                                shards[r][0]) for r in range(world)]), dim=0).contiguous()
+        np.testing.assert_allclose(row_lse.cpu().numpy(), ko.log_softmax(ref["outputs"])[:, 0] * -1 + ref["outputs"][:, 0],
+                                   rtol=2e-6, atol=2e-6)
     for r in range(world):
         sh, first, n = shards[r]
-        local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
-                              pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=first, n_cand=n,
-                              drop_cand=batch.drop_cand)
+        local = local_batch(r)
         dE, dq = torch.zeros_like(Es[r]), torch.empty_like(qe[0])
-        losses.append(hp.train_tiles(Es[r], Rt, SCORER, qe[0], local, sh, dE, dq, N_ENT - 2,
-                                     normalizer=float(batch.B) * (N_ENT - 2), grads_zero=True).clone())
+        losses.append(hp.train_tiles(Es[r], Rt, SCORER, qe[0], local, sh, dE, dq, N_ENT - 2, loss=loss,
+                                     normalizer=float(batch.B) * (N_ENT - 2), grads_zero=True,
+                                     row_lse=row_lse).clone())
         dEs.append(dE)
         dqs.append(dq)
     dq = sum(dqs)
@@ -166,6 +220,42 @@ def test_three_phase_abi_emulated_shards(world, okge_lib):
     np.testing.assert_allclose(dE, ref["dE"], rtol=0, atol=3e-5 * np.abs(ref["dE"]).max())
     for dR in dRs:
         np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_ranks_emulated_shards(world, okge_lib):
+    """score_queries + group_true_scores ("all-reduce max") + rank_counts ("all-reduce sum") over emulated shards
+    == the single-device score + filtered_ranks, bit for bit; and == the oracle up to float near-ties."""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.sharded import shard_range
+    hp = H.HotPath("cuda:0")
+    E, R = tables()
+    eb = eval_problem()
+    batch = to_batch(eb, "cuda:0")
+    Et, Rt = torch.from_numpy(E).cuda(), torch.from_numpy(R).cuda()
+    dev = lambda k: torch.from_numpy(eb[k]).cuda()      # noqa: E731
+    fp, fc, rp, gp, ids = dev("filt_ptr"), dev("filt_col"), dev("row_ptr"), dev("grp_ptr"), dev("ids")
+    whole = hp.filtered_ranks(hp.score(Et, Rt, SCORER, batch), fp, fc, rp, gp, ids).cpu().numpy()
+    shards, xs = [], []
+    for r in range(world):
+        lo, hi = shard_range(N_ENT, world, r)
+        c_lo = max(lo, 2)
+        sh = H.Shard(lo, hi, c_lo - 2)
+        shards.append(sh)
+        xs.append((Et[lo:hi].contiguous(), c_lo - lo, hi - c_lo))
+    qe = sum(hp.encode_queries(xs[r][0], Rt, SCORER, batch, shards[r]) for r in range(world))
+    scores = []
+    for r in range(world):
+        local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
+                              cand_first=xs[r][1], n_cand=xs[r][2])
+        scores.append(hp.score_queries(xs[r][0], Rt, SCORER, qe[0], batch.B, local, shards[r]))
+    true = torch.stack([hp.group_true_scores(scores[r], shards[r].cand_col0, rp, gp, ids) for r in range(world)]).max(0).values
+    counts = sum(hp.rank_counts(scores[r], shards[r].cand_col0, fp, fc, rp, true) for r in range(world))
+    ranks = (counts[:, 0] + counts[:, 1] // 2).cpu().numpy()
+    np.testing.assert_array_equal(ranks, whole)
+    ref = oracle_ranks(eb)
+    assert (ranks != ref).mean() < 0.01 and np.abs(ranks - ref).max() <= 1
 
 
 @pytest.mark.gpu
