@@ -80,6 +80,10 @@ class PrefixBatch:
     def nnz(self):
         return 0 if self.pos_row is None else int(self.pos_row.numel())
 
+    @property
+    def n_candidates(self):
+        return int(self.n_cand if self.cand_ids is None else self.cand_ids.numel())
+
 
 @dataclass
 class Shard:

@@ -25,6 +25,7 @@ import torch
 import torch.distributed as dist
 
 from . import hotpath as H
+from .train_step import FusedTrainStep
 
 
 def shard_range(n_ent, world, rank):
@@ -143,3 +144,36 @@ class ShardedEvaluator:
         counts = eng.rank_counts(x, self.col0, filt_ptr, filt_col, row_ptr, true)
         dist.all_reduce(counts, group=self.group)
         return counts[:, 0] + counts[:, 1] // 2
+
+
+class ReplicaTrainStep(FusedTrainStep):
+    """Replicas (last row): batch-shared sampled candidate lists (1-vs-N with N of a few
+    thousand, dataset.py:853-860) are too short to shard, so every rank keeps both tables whole, runs the fused
+    step on ITS OWN batch (own prefixes, own candidate list, own dropout stream) and the dense gradients are
+    averaged with ONE all-reduce over a flat buffer holding dE and dR back to back; the Adagrad sweep then applies
+    the same update everywhere, so the replicas never drift.  The reference's nn.DataParallel branch
+    (trainer.py:143-145) is the closest counterpart."""
+
+    def __init__(self, E, R, scorer, group=None, **kw):
+        super().__init__(E, R, scorer, **kw)
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        n_e = (E.numel() + 3) // 4 * 4                       # keep dR 16-byte aligned for the Adagrad sweep
+        self.flat_grad = torch.zeros(n_e + R.numel(), dtype=E.dtype, device=E.device)
+        self.dE = self.flat_grad[:E.numel()].view_as(E)
+        self.dR = self.flat_grad[n_e:].view_as(R)
+        self.seed = self.seed + 1000003 * self.rank          # independent dropout masks per replica
+
+    def step(self, batch: H.PrefixBatch, normalizer=None):
+        self.steps += 1
+        if normalizer is None:
+            normalizer = float(batch.B) * float(batch.n_candidates)
+        loss = self.forward_backward(batch, normalizer * self.world)       # mean over replicas
+        dist.all_reduce(self.flat_grad, group=self.group)
+        loss_work = dist.all_reduce(loss, group=self.group, async_op=True)
+        self._grads_zero = False
+        self.optimizer_step()
+        self._grads_zero = True
+        loss_work.wait()
+        return loss

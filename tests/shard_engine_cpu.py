@@ -130,6 +130,27 @@ class OracleShardEngine:
         loss_out[0] = lsum
         return loss_out
 
+    def forward_backward(self, E, R, scorer, batch, dE, dR, loss="bce", label_smoothing=0.0, normalizer=None,
+                         loss_out=None, scores=None, grads_zero=False, loss_only=False):
+        """the whole fused call (replica mode): oracle step on this rank's batch"""
+        En, Rn = _np(E), _np(R)
+        d = En.shape[1]
+        cand = _np(batch.cand_ids) if batch.cand_ids is not None else np.arange(batch.cand_first, batch.cand_first + batch.n_cand)
+        n = len(cand)
+        y = np.zeros((batch.B, n), np.float32)
+        y[_np(batch.pos_row), _np(batch.pos_col)] = 1
+        p = batch.drop_cand.p
+        out = ko.step_forward_backward(
+            ko.KIND_NAMES[scorer], En, Rn, (_np(batch.po_rel), _np(batch.po_obj)) if batch.n_po else None,
+            (_np(batch.sp_subj), _np(batch.sp_rel)) if batch.n_sp else None, cand, y,
+            loss_kind=ko.LOSS_KL if loss == "kl" else ko.LOSS_BCE, smoothing=label_smoothing, normalizer=normalizer,
+            p_ent=p, keep_cand=_keep(batch.drop_cand, n, d), keep_po_ent=_keep(batch.drop_po_ent, batch.n_po, d),
+            keep_sp_ent=_keep(batch.drop_sp_ent, batch.n_sp, d))
+        dE += torch.from_numpy(out["dE"])
+        dR += torch.from_numpy(out["dR"])
+        loss_out[0] = out["loss"]
+        return loss_out
+
     def prefix_backward(self, E_local, R, scorer, batch, shard, dQ, ent_rows, dE, dR):
         kind = ko.KIND_NAMES[scorer]
         d = E_local.shape[1]

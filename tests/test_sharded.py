@@ -150,6 +150,73 @@ def test_sharded_exchange_protocol_gloo(world, loss):
     np.testing.assert_array_equal(parts[0]["R"], parts[1]["R"])
 
 
+def replica_problem(rank, step):
+    """per-rank batch with its own sampled candidate list (batch-shared 1-vs-N, duplicates allowed)"""
+    rng = np.random.default_rng(1000 * rank + step)
+    b = problem(10 * rank + step)
+    cand = rng.integers(2, N_ENT, 96).astype(np.int32)
+    y = np.zeros((N_PO + N_SP, len(cand)), np.float32)
+    for r in range(N_PO + N_SP):
+        y[r, rng.choice(len(cand), size=int(rng.integers(1, 4)), replace=False)] = 1
+    col, row = np.nonzero(y.T)
+    b.update(cand=cand, labels=y, pos_col=col.astype(np.int32), pos_row=row.astype(np.int32))
+    return b
+
+
+def _replica_worker(rank, world, port, outdir, nsteps):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaTrainStep
+    from shard_engine_cpu import OracleShardEngine
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    E, R = tables()
+    st = ReplicaTrainStep(torch.from_numpy(E.copy()), torch.from_numpy(R.copy()), SCORER, lr=LR, engine=OracleShardEngine())
+    t = torch.from_numpy
+    losses = []
+    for step in range(1, nsteps + 1):
+        b = replica_problem(rank, step)
+        batch = PrefixBatch(po_rel=t(b["po_rel"]), po_obj=t(b["po_obj"]), sp_subj=t(b["sp_subj"]), sp_rel=t(b["sp_rel"]),
+                            pos_row=t(b["pos_row"]), pos_col=t(b["pos_col"]), cand_ids=t(b["cand"]))
+        losses.append(float(st.step(batch)[0]))
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), E=st.E.numpy(), R=st.R.numpy(), losses=np.asarray(losses))
+    dist.destroy_process_group()
+
+
+def test_replica_step_gloo():
+    """Two replicas with different batches == one process averaging the two oracle gradients, then Adagrad."""
+    import torch.multiprocessing as mp
+    world, nsteps = 2, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_replica_worker, args=(world, port, outdir, nsteps), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
+    E, R = tables()
+    sE, sR = np.zeros_like(E), np.zeros_like(R)
+    losses = []
+    for step in range(1, nsteps + 1):
+        dE, dR, ls = np.zeros_like(E), np.zeros_like(R), 0.0
+        for rank in range(world):
+            b = replica_problem(rank, step)
+            out = ko.step_forward_backward(ko.KIND_NAMES[SCORER], E, R, (b["po_rel"], b["po_obj"]), (b["sp_subj"], b["sp_rel"]),
+                                           b["cand"], b["labels"], normalizer=float(world * b["labels"].size))
+            dE += out["dE"]
+            dR += out["dR"]
+            ls += out["loss"]
+        ko.adagrad_step(E, dE, sE, LR)
+        ko.adagrad_step(R, dR, sR, LR)
+        losses.append(ls)
+    np.testing.assert_array_equal(parts[0]["E"], parts[1]["E"])          # replicas never drift
+    np.testing.assert_array_equal(parts[0]["R"], parts[1]["R"])
+    np.testing.assert_allclose(parts[0]["losses"], losses, rtol=1e-6)
+    close = np.isclose(parts[0]["E"], E, rtol=2e-4, atol=2e-5)
+    assert close.mean() > 0.999 and np.abs(parts[0]["E"] - E).max() < 5e-3
+    np.testing.assert_allclose(parts[0]["R"], R, rtol=2e-4, atol=2e-5)
+
+
 def test_shard_ranges_cover_table():
     from open_knowledge_graph_embeddings_amd.sharded import shard_range
     for n, w in ((14543, 8), (301, 3), (10, 4), (2_500_000, 8)):
@@ -284,5 +351,35 @@ def test_sharded_step_one_rank_equals_fused_step(okge_lib):
         # (tests/test_oracle_golden.py::adagrad_tol), so a handful of elements may sit further out
         close = np.isclose(a.E.cpu().numpy(), E_ref, rtol=1e-3, atol=1e-4)
         assert close.mean() > 0.999 and np.abs(a.E.cpu().numpy() - E_ref).max() < 5e-3
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replica_step_one_rank_equals_fused_step(okge_lib):
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaTrainStep
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        E, R = tables()
+        mk = lambda cls, **kw: cls(torch.from_numpy(E.copy()).cuda(), torch.from_numpy(R.copy()).cuda(), SCORER,   # noqa: E731
+                                   lr=LR, input_dropout=P_DROP, seed=SEED, **kw)
+        a, f = mk(ReplicaTrainStep), mk(FusedTrainStep)
+        t = lambda x: torch.from_numpy(x).cuda()      # noqa: E731
+        for step in range(1, 4):
+            b = replica_problem(0, step)
+            for st in (a, f):
+                batch = PrefixBatch(po_rel=t(b["po_rel"]), po_obj=t(b["po_obj"]), sp_subj=t(b["sp_subj"]), sp_rel=t(b["sp_rel"]),
+                                    pos_row=t(b["pos_row"]), pos_col=t(b["pos_col"]), cand_ids=t(b["cand"]))
+                st.step(batch)
+        torch.cuda.synchronize()
+        assert float(a.loss_out[0]) == float(f.loss_out[0])
+        np.testing.assert_array_equal(a.E.cpu().numpy(), f.E.cpu().numpy())
+        np.testing.assert_array_equal(a.R.cpu().numpy(), f.R.cpu().numpy())
     finally:
         dist.destroy_process_group()
