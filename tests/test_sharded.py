@@ -378,8 +378,9 @@ def test_replica_step_one_rank_equals_fused_step(okge_lib):
                                     pos_row=t(b["pos_row"]), pos_col=t(b["pos_col"]), cand_ids=t(b["cand"]))
                 st.step(batch)
         torch.cuda.synchronize()
-        assert float(a.loss_out[0]) == float(f.loss_out[0])
-        np.testing.assert_array_equal(a.E.cpu().numpy(), f.E.cpu().numpy())
-        np.testing.assert_array_equal(a.R.cpu().numpy(), f.R.cpu().numpy())
+        # duplicate candidate ids accumulate with atomics: same sums, run-dependent order
+        assert abs(float(a.loss_out[0]) - float(f.loss_out[0])) <= 1e-6 * abs(float(f.loss_out[0]))
+        np.testing.assert_allclose(a.E.cpu().numpy(), f.E.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(a.R.cpu().numpy(), f.R.cpu().numpy(), rtol=1e-4, atol=1e-5)
     finally:
         dist.destroy_process_group()
