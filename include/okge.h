@@ -194,6 +194,12 @@ size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d);
 int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const int32_t *ids, int32_t first_id,
                      int32_t n, const okge_dropout *drop, float *out, int64_t ld_out, void *stream);
 
+/* Per-triple scores of ENCODED rows, Hadamard form: RelationScorer.triple_score / forward(subj, rel, obj)
+ * (model.py:43-50; ComplEx :231-238  sum s1 r1 o1 + s2 r1 o2 + s1 r2 o2 - s2 r2 o1;  DistMult :276  sum s r o).
+ * Inference helper: the reference trains through the prefix path only (trainer.py:59-64). */
+int okge_score_triples(int32_t scorer, const float *subj, int64_t ld_subj, const float *rel, int64_t ld_rel,
+                       const float *obj, int64_t ld_obj, int32_t n, int32_t d, float *out, void *stream);
+
 /* x[i] *= *alpha_dev for i < n (alpha is a DEVICE fp32 scalar: the upstream gradient autograd hands to the
  * fused loss node, i.e. 1/normalizer of trainer.py:221, without a host synchronisation). */
 int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream);

@@ -28,7 +28,7 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
-           "okge_rank_counts", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_rank_counts", "okge_score_triples", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -135,6 +135,9 @@ def lib():
     L.okge_encode_rows.restype = c_int32
     L.okge_encode_rows.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, POINTER(Dropout), c_void_p,
                                    c_int64, c_void_p]
+    L.okge_score_triples.restype = c_int32
+    L.okge_score_triples.argtypes = [c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
+                                     c_void_p, c_void_p]
     L.okge_scale_inplace.restype = c_int32
     L.okge_scale_inplace.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.okge_adagrad_step.restype = c_int32

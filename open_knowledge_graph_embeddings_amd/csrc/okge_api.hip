@@ -547,6 +547,20 @@ int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const in
     return OKGE_OK;
 }
 
+int okge_score_triples(int32_t scorer, const float *subj, int64_t ld_subj, const float *rel, int64_t ld_rel,
+                       const float *obj, int64_t ld_obj, int32_t n, int32_t d, float *out, void *stream)
+{
+    if (!subj || !rel || !obj || !out || n < 0 || d <= 0 || ld_subj < d || ld_rel < d || ld_obj < d)
+        return fail(OKGE_ERR_INVALID, "bad score_triples arguments");
+    if (scorer != OKGE_COMPLEX && scorer != OKGE_DISTMULT) return fail(OKGE_ERR_INVALID, "unknown scorer");
+    if (scorer == OKGE_COMPLEX && (d & 1)) return fail(OKGE_ERR_INVALID, "ComplEx needs an even slot size");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("score_triples", st);
+    hipError_t e = launch_score_triples(subj, ld_subj, rel, ld_rel, obj, ld_obj, n, d, scorer, out, st);
+    if (e != hipSuccess) return fail_hip(e, "score_triples");
+    return OKGE_OK;
+}
+
 int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream)
 {
     if (!x || !alpha_dev || n < 0) return fail(OKGE_ERR_INVALID, "bad scale arguments");

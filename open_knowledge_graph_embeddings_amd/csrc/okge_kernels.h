@@ -76,6 +76,8 @@ hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, f
                           hipStream_t st);
 hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p1, float *g1, float *s1, int64_t n1,
                            float lr, float wd, float eps, int zero_grad, hipStream_t st);
+hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
+                                int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, int col0, const float *true_in, float *true_out, int64_t *counts_out,

@@ -521,7 +521,39 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
     }
 }
 
+// Per-triple score of already encoded rows, Hadamard form (model.py:231-238, :276): one wave per triple.
+__global__ __launch_bounds__(256) void score_triples_kernel(const float *__restrict__ S, int64_t lds_,
+                                                            const float *__restrict__ Rr, int64_t ldr,
+                                                            const float *__restrict__ O, int64_t ldo, int n, int d,
+                                                            int scorer, float *__restrict__ out)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const float *s = S + (size_t)i * lds_, *r = Rr + (size_t)i * ldr, *o = O + (size_t)i * ldo;
+    float acc = 0.f;
+    if (scorer == SC_DISTMULT) {
+        for (int k = lane; k < d; k += 64) acc += s[k] * o[k] * r[k];
+    } else {
+        const int h = d >> 1;
+        for (int k = lane; k < h; k += 64) {
+            const float s1 = s[k], s2 = s[h + k], r1 = r[k], r2 = r[h + k], o1 = o[k], o2 = o[h + k];
+            acc += s1 * o1 * r1 + s2 * o2 * r1 + s1 * o2 * r2 - s2 * o1 * r2;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = acc;
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------
+hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
+                                int n, int d, int scorer, float *out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(score_triples_kernel, dim3((n + 3) / 4), dim3(256), 0, st, S, lds_, Rr, ldr, O, ldo, n, d, scorer,
+                       out);
+    return hipGetLastError();
+}
+
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
                                  int tiles, int tile_w, int cand_col0, hipStream_t st)

@@ -287,6 +287,20 @@ class HotPath:
                                               self._stream()), "okge_prefix_backward")
         del keep
 
+    def score_triples(self, scorer, subj, rel, obj):
+        """(b, 1) scores of b encoded triples (rows (b, d), last dim contiguous): triple_score (model.py:178-179)."""
+        rows = [x.reshape(-1, x.shape[-1]) for x in (subj, rel, obj)]
+        b, d = rows[0].shape
+        for x in rows:
+            if x.dtype != torch.float32 or x.stride(1) != 1 or x.device != self.device or x.shape != (b, d):
+                raise N.OkgeError("triple rows must be fp32 (b, d) on the engine's device with a contiguous last dim")
+        out = torch.empty((b, 1), dtype=torch.float32, device=self.device)
+        N.check(self.lib.okge_score_triples(N.SCORERS[scorer] if isinstance(scorer, str) else int(scorer),
+                                            rows[0].data_ptr(), rows[0].stride(0), rows[1].data_ptr(), rows[1].stride(0),
+                                            rows[2].data_ptr(), rows[2].stride(0), b, d, out.data_ptr(), self._stream()),
+                "okge_score_triples")
+        return out
+
     def encode_rows(self, table, ids=None, first_id=0, n=None, drop: DropoutSpec = NO_DROP, out=None):
         """dropout(table[ids]) -> (n, d): LookupBaseRelationEmbedder._encode (model.py:455-480)."""
         ids = _i32(ids, self.device)

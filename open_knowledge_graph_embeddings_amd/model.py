@@ -44,9 +44,9 @@ class RelationScorer(RelationModel):
         return self.triple_score(self.encode_subj(subj), self.encode_rel(rel), self.encode_obj(obj), **kwargs)
 
     def triple_score(self, subj, rel, obj, **kwargs):
-        # model.py:178-179, :231-238 / :245-246, :276 -- the per-triple Hadamard form is not on the prefix-scoring
-        # path (trainer.py:64 returns None for input_style 'triple'); not provided.
-        raise NotImplementedError("triple scoring is outside the fused prefix-scoring path")
+        """(b, 1) scores of encoded triples, Hadamard form (model.py:178-179, :231-238, :276).  Inference helper:
+        the reference trains through the prefix path only (trainer.py:59-64), so no gradient is defined here."""
+        return self.engine().score_triples(self.scorer_name, subj, rel, obj)
 
     def sp_prefix_score(self, subj=None, rel=None, many_obj=None):
         """scores (b, N) of (subj, rel, ?) against all objects, or against pre-encoded rows `many_obj`."""

@@ -93,6 +93,16 @@ def score_prefix_4mm(kind, direction, ent, rel, cand):
     return (a1 * r1) @ c1.T + (a2 * r1) @ c2.T + (a2 * r2) @ c1.T - (a1 * r2) @ c2.T
 
 
+def score_triples(kind, subj, rel, obj):
+    """(b,) scores of b encoded triples, Hadamard form (model.py:231-238 ComplEx, :276 DistMult):
+    ComplEx  sum s1*r1*o1 + s2*r1*o2 + s1*r2*o2 - s2*r2*o1,  DistMult  sum s*r*o."""
+    if kind == DISTMULT:
+        return (subj * obj * rel).sum(axis=1)
+    h = subj.shape[1] // 2
+    s1, s2, r1, r2, o1, o2 = subj[:, :h], subj[:, h:], rel[:, :h], rel[:, h:], obj[:, :h], obj[:, h:]
+    return (s1 * o1 * r1 + s2 * o2 * r1 + s1 * o2 * r2 - s2 * o1 * r2).sum(axis=1)
+
+
 def score_prefix(kind, direction, ent, rel, cand):
     """(b, N) scores of b prefixes against N candidate rows = query @ cand.T."""
     return prefix_query(kind, direction, ent, rel) @ cand.T

@@ -13,6 +13,7 @@ scores, losses, gradients, updated weights, ranks); no reference source is copie
 
 Vectors:
   g1_scores_*     sp_prefix_score / po_prefix_score, ComplEx + DistMult, dropout 0
+  g1_triples_*    forward(subj, rel, obj) = triple_score of the encoded rows (Hadamard form)
   g2_loss_*       AddLossModule forward + (loss/normalizer).backward(): loss, all_outputs, dE, dR
                   (bce, bce + label smoothing, kl, one direction None, batch-shared candidates,
                   input_dropout 0.4 with the Bernoulli masks captured)
@@ -92,6 +93,19 @@ def g1():
                  E=npy(m.entity_embedding.weight), R=npy(m.relation_embedding.weight),
                  subj=npy(subj), rel_sp=npy(rel_sp), rel_po=npy(rel_po), obj=npy(obj), cand=npy(cand),
                  sp_all=npy(sp_all), po_all=npy(po_all), sp_cand=npy(sp_c), po_cand=npy(po_c))
+
+
+def g1_triples():
+    for mname, tag in (("LookupComplexRelationModel", "complex"), ("LookupDistmultRelationModel", "distmult")):
+        for (n_ent, n_rel, d, b, case) in ((66, 10, 16, 9, "tiny"), (301, 17, 200, 33, "d200")):
+            rng = np.random.default_rng(4000 + d)
+            m = make_model(mname, n_ent, n_rel, d, seed=41 + d)
+            m.eval()
+            subj, rel, obj = rand_ids(rng, 2, n_ent, b), rand_ids(rng, 2, n_rel, b), rand_ids(rng, 2, n_ent, b)
+            with torch.no_grad():
+                out = m(subj, rel, obj)
+            save(f"g1_triples_{tag}_{case}", E=npy(m.entity_embedding.weight), R=npy(m.relation_embedding.weight),
+                 subj=npy(subj), rel=npy(rel), obj=npy(obj), scores=npy(out))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -355,9 +369,8 @@ def g7():
 
 
 if __name__ == "__main__":
-    g1()
-    g2()
-    g3()
-    g5()
-    g7()
+    only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
+    for fn in (g1, g1_triples, g2, g3, g5, g7):
+        if not only or fn.__name__ in only:
+            fn()
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -90,6 +90,21 @@ def test_prefix_score_methods(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_names("g1_triples_"))
+def test_forward_triple_score(name):
+    """model(subj, rel, obj) = triple_score(encode_subj, encode_rel, encode_obj) (model.py:43-50)."""
+    z = golden(name)
+    cls = "LookupComplexRelationModel" if "complex" in name else "LookupDistmultRelationModel"
+    m = make_model(cls, z["E"], z["R"], "cuda:0").eval()
+    dev = lambda a: torch.from_numpy(a).to("cuda:0")        # noqa: E731
+    out = m(dev(z["subj"]), dev(z["rel"]), dev(z["obj"]))
+    assert out.shape == z["scores"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), z["scores"], rtol=0, atol=2e-6)
+    out2 = m._score(m.encode_subj(dev(z["subj"])), m.encode_rel(dev(z["rel"])), m.encode_obj(dev(z["obj"])))
+    np.testing.assert_array_equal(out2.cpu().numpy(), out.cpu().numpy())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", [n for n in golden_names("g2_loss_") if "dropout" not in n])
 def test_add_loss_module_forward_backward(name):
     """AddLossModule.forward + (loss.sum()/normalizer).backward() exactly as Trainer.compute_one_batch drives it."""

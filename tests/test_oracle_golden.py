@@ -35,6 +35,14 @@ def test_g1_scores(name):
         np.testing.assert_allclose(po4, z[po_key], rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("name", golden_names("g1_triples_"))
+def test_g1_triples(name):
+    z = golden(name)
+    kind = ko.COMPLEX if "complex" in name else ko.DISTMULT
+    out = ko.score_triples(kind, ko.encode(z["E"], z["subj"]), ko.encode(z["R"], z["rel"]), ko.encode(z["E"], z["obj"]))
+    np.testing.assert_allclose(out[:, None], z["scores"], rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("name", ["g1_scores_complex_tiny", "g1_scores_distmult_tiny", "g1_scores_complex_odd"])
 def test_g1_scores_c_oracle(name):
     z = golden(name)
