@@ -268,6 +268,89 @@ def metrics_from_ranks(ranks, row_ptr):
 
 
 # ------------------------------------------------------------------------------------------------
+# batch producer                          openkge/dataset.py:724-940 (OneToNMentionRelationDataset_collate_func)
+#                                         utils/misc.py:56-89 (packed answer groups)
+# ------------------------------------------------------------------------------------------------
+def pack_groups(groups):
+    """utils/misc.py:56-70.  k answer groups -> [b_0+L, ..., b_k+L, 0, ids...] with b_0 = 0, b_i = cumulative
+    group lengths and L = k+2 the header length: header entries are slice-relative positions, 0 ends the header."""
+    offsets, ids = [0], []
+    for g in groups:
+        ids.extend(g if isinstance(g, (list, tuple)) else [g])
+        offsets.append(len(ids))
+    L = len(offsets) + 1
+    return [o + L for o in offsets] + [0] + ids
+
+
+def unpack_groups(packed):
+    """utils/misc.py:72-89 -> (list of groups, flat id list)."""
+    packed = [int(x) for x in packed]
+    header = []
+    for off in packed:
+        if off == 0:
+            break
+        header.append(off)
+    groups = [packed[a:b] for a, b in zip(header[:-1], header[1:])]
+    flat = packed[header[0]:header[-1]] if len(header) > 1 else []
+    return groups, flat
+
+
+def collate_batch(rows, seen_entities, all_splits_entities, n_entities, entity_offset, is_training,
+                  use_batch_shared, min_size_batch_labels=0, negatives=None):
+    """dataset.py:724-940 on one batch of (P,7) prefix rows [a, b, this_start, this_end, all_start, all_end, slot].
+
+    Returns dict:
+      po = (rel[b0], obj[b0]) or None   slot 0 rows, batch order      (dataset.py:884-891,932)
+      sp = (subj[b1], rel[b1]) or None  slot 2 rows
+      labels  : sorted unique (row, col) pairs, rows numbered po-first (the dense label tensor as coordinates)
+      groups  : per row, list of groups of candidate-relative ids       (label_ids, evaluation only)
+      filters : per row, sorted unique candidate positions              (filter_mask rows, evaluation only)
+      cand    : candidate entity ids in column order
+      normalizer_loss = B*N, normalizer_metric = number of labels       (dataset.py:934-935)
+    `negatives`: the already sampled fill-up ids in the order they are appended (dataset.py:853-860 takes them
+    from a Python set, whose order is an implementation detail; callers replay the reference's order or use
+    their own sampler)."""
+    items = {0: [], 2: []}
+    index = {}                                     # batch-shared: entity id -> column, in first-seen order
+    for row in rows:
+        a, b, ts, te, as_, ae, slot = (int(x) for x in row)
+        groups, flat = unpack_groups(seen_entities[ts:te])
+        everything = [int(x) for x in all_splits_entities[as_:ae]]
+        items[slot].append(((a, b), groups, flat, everything))
+        if use_batch_shared:
+            for e in (flat if is_training else everything):
+                index.setdefault(e, len(index))
+    if use_batch_shared:
+        m = max(0, min_size_batch_labels or 0)
+        if len(index) >= m:
+            cand = list(index)
+        else:
+            extra = [int(x) for x in (negatives if negatives is not None else [])]
+            cand = (list(index) + [e for e in extra if e not in index])[:m]
+        col = index.__getitem__
+    else:
+        cand = list(range(entity_offset, n_entities))
+        col = lambda e: e - entity_offset                  # noqa: E731
+    labels, groups_out, filters, parts = set(), [], [], {}
+    r = 0
+    for slot in (0, 2):
+        parts[slot] = None
+        if not items[slot]:
+            continue
+        parts[slot] = (np.asarray([it[0][0] for it in items[slot]], np.int32),
+                       np.asarray([it[0][1] for it in items[slot]], np.int32))
+        for _, groups, flat, everything in items[slot]:
+            labels.update((r, col(e)) for e in flat)
+            if not is_training:
+                groups_out.append([[col(e) for e in g] for g in groups])
+                filters.append(sorted({col(e) for e in everything}))
+            r += 1
+    return dict(po=parts[0], sp=parts[2], labels=sorted(labels), groups=groups_out, filters=filters,
+                cand=np.asarray(cand, np.int32), normalizer_loss=float(r * len(cand)),
+                normalizer_metric=float(len(labels)))
+
+
+# ------------------------------------------------------------------------------------------------
 # counter-based dropout masks (this build's replacement for torch's bernoulli_, SURVEY.md 'hard
 # parts'): Philox4x32-10, key = seed, counter = (row, column/8, stream, step).  Integer work ->
 # the HIP kernels reproduce these masks bit for bit.

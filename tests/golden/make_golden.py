@@ -18,6 +18,8 @@ Vectors:
                   (bce, bce + label smoothing, kl, one direction None, batch-shared candidates,
                   input_dropout 0.4 with the Bernoulli masks captured)
   g3_adagrad_*    three optimisation steps through utils.optim.OptimRegime (Adagrad, leaked eps)
+  g4_collate_*    OneToNMentionRelationDataset_collate_func on packed toy prefix tables: 1-vs-all and batch-shared,
+                  training and evaluation, with and without numpy-sampled fill-up negatives
   g5_ranks_*      OneToNMentionRelationDataset.compute_metrics (known answer + ties + mention groups)
   g7_traj_*       20 training steps, fixed batches -> loss curve and final tables
 """
@@ -368,9 +370,72 @@ def g7():
     save("g7_traj_complex", **kw)
 
 
+# ----------------------------------------------------------------------------------------------
+# G4: the batch producer (collate) on packed prefix tables
+# ----------------------------------------------------------------------------------------------
+def g4():
+    import numpy
+    from openkge.dataset import OneToNMentionRelationDataset_collate_func as collate
+    from utils.misc import pack_list_of_lists
+
+    rng = np.random.default_rng(44)
+    n_ent, off = 60, 2
+    seen, allsp, rows = [], [], []
+    for i in range(40):
+        slot = 0 if rng.random() < 0.5 else 2
+        k = int(rng.integers(1, 5))
+        groups = [rng.integers(off, n_ent, size=int(rng.integers(1, 4))).tolist() for _ in range(k)]   # mentions; repeats allowed
+        packed = pack_list_of_lists(groups)
+        flat = sorted({e for g in groups for e in g})
+        extra = rng.integers(off, n_ent, size=int(rng.integers(0, 4))).tolist()
+        everything = list(dict.fromkeys(flat + extra))                       # unique, as the merged splits are (a set)
+        rng.shuffle(everything)
+        rows.append([int(rng.integers(2, 9)), int(rng.integers(2, n_ent)), len(seen), len(seen) + len(packed),
+                     len(allsp), len(allsp) + len(everything), slot])
+        seen += packed
+        allsp += everything
+    seen_t, all_t, rows_t = torch.IntTensor(seen), torch.IntTensor(allsp), torch.IntTensor(rows)
+    kw = dict(seen=np.asarray(seen, np.int32), all_splits=np.asarray(allsp, np.int32), prefixes=np.asarray(rows, np.int32),
+              n_ent=np.int64(n_ent), offset=np.int64(off))
+    batches = [list(range(0, 12)), list(range(12, 40, 3)), [5], [i for i in range(40) if rows[i][6] == 0][:6]]
+    ncase = 0
+    for shared, min_size in ((False, 0), (True, 0), (True, 48), (True, -1)):
+        for training in (True, False):
+            for bi, idx in enumerate(batches):
+                numpy.random.seed(7 + bi)
+                out = collate(use_batch_shared_entities=shared, sp_po__batch=[rows_t[i] for i in idx],
+                              entity_vocab_size=n_ent, entity_vocab_offset=off, is_training_data=training,
+                              this_split_entities_list=seen_t, all_splits_entities_tensor=all_t,
+                              min_size_batch_labels=min_size)
+                inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = out
+                tag = f"c{ncase}_"
+                kw[tag + "rows"] = np.asarray(idx, np.int64)
+                kw[tag + "cfg"] = np.asarray([int(shared), min_size, int(training)], np.int64)
+                for name, part in zip(("po", "sp"), inputs):
+                    kw[tag + name] = (np.zeros((0, 2), np.int32) if part is None
+                                      else np.concatenate([npy(part[0]), npy(part[1])], axis=1))
+                kw[tag + "labels"] = npy(labels.nonzero()).astype(np.int32)                 # (nnz, 2) row, col
+                kw[tag + "shape"] = np.asarray(labels.shape, np.int64)
+                kw[tag + "norm"] = np.asarray([norm_loss, norm_metric], np.float64)
+                kw[tag + "cand"] = npy(cand).reshape(-1)
+                if not training:
+                    kw[tag + "filter"] = npy(filt.nonzero()).astype(np.int32)
+                    gp, ids, rp = [0], [], [0]
+                    for row_groups in label_ids:
+                        for g in row_groups:
+                            ids += npy(g).reshape(-1).tolist()
+                            gp.append(len(ids))
+                        rp.append(len(gp) - 1)
+                    kw[tag + "row_ptr"], kw[tag + "grp_ptr"] = np.asarray(rp, np.int64), np.asarray(gp, np.int64)
+                    kw[tag + "ids"] = np.asarray(ids, np.int32)
+                ncase += 1
+    kw["n_cases"] = np.int64(ncase)
+    save("g4_collate_toy", **kw)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g5, g7):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g7):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -261,3 +261,53 @@ def test_philox_known_answer():
 def test_philox_keep_rate():
     m = ko.dropout_keep_mask(7, 0, 0, 2000, 200, 0.4)
     assert abs(m.mean() - 0.6) < 0.005
+
+
+# ---------------------------------------------------------------------------------------------- G4
+def collate_cases():
+    z = golden("g4_collate_toy")
+    for c in range(int(z["n_cases"])):
+        t = f"c{c}_"
+        shared, min_size, training = (int(x) for x in z[t + "cfg"])
+        yield z, t, bool(shared), min_size, bool(training)
+
+
+def test_g4_pack_roundtrip():
+    groups = [[7], [3, 4, 3], [9, 9]]
+    packed = ko.pack_groups(groups)
+    assert packed == [5, 6, 9, 11, 0, 7, 3, 4, 3, 9, 9]           # L = k+2 = 5 header slots
+    assert ko.pack_groups([[1], [2], [3]]) == [5, 6, 7, 8, 0, 1, 2, 3]
+    assert ko.unpack_groups(packed) == (groups, [7, 3, 4, 3, 9, 9])
+
+
+def test_g4_collate_oracle_matches_reference():
+    n = 0
+    for z, t, shared, min_size, training in collate_cases():
+        rows = z["prefixes"][z[t + "rows"]]
+        n_idx = None
+        if shared:       # replay the reference's fill-up order (a Python set's iteration order, dataset.py:853-860)
+            probe = ko.collate_batch(rows, z["seen"], z["all_splits"], int(z["n_ent"]), int(z["offset"]), training, True, 0)
+            n_idx = len(probe["cand"])
+        out = ko.collate_batch(rows, z["seen"], z["all_splits"], int(z["n_ent"]), int(z["offset"]), training, shared,
+                               min_size, negatives=None if n_idx is None else z[t + "cand"][n_idx:])
+        np.testing.assert_array_equal(out["cand"], z[t + "cand"])
+        for name in ("po", "sp"):
+            got = np.zeros((0, 2), np.int32) if out[name] is None else np.stack(out[name], axis=1)
+            np.testing.assert_array_equal(got, z[t + name])
+        np.testing.assert_array_equal(np.asarray(out["labels"], np.int32).reshape(-1, 2), z[t + "labels"])
+        assert [out["normalizer_loss"], out["normalizer_metric"]] == z[t + "norm"].tolist()
+        assert (len(rows), len(out["cand"])) == tuple(z[t + "shape"])
+        if not training:
+            filt = [(r, c) for r, cols in enumerate(out["filters"]) for c in cols]
+            np.testing.assert_array_equal(np.asarray(filt, np.int32).reshape(-1, 2), z[t + "filter"])
+            gp, ids, rp = [0], [], [0]
+            for row_groups in out["groups"]:
+                for g in row_groups:
+                    ids += g
+                    gp.append(len(ids))
+                rp.append(len(gp) - 1)
+            np.testing.assert_array_equal(rp, z[t + "row_ptr"])
+            np.testing.assert_array_equal(gp, z[t + "grp_ptr"])
+            np.testing.assert_array_equal(np.asarray(ids, np.int32), z[t + "ids"])
+        n += 1
+    assert n == 32
