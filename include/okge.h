@@ -132,6 +132,10 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
 /*               OKGE_TRAIN_LOSS_ONLY  -- forward + loss only (validation loss under torch.no_grad(),
  *               trainer.py:363-369): dE/dR are not touched and may be NULL */
 #define OKGE_TRAIN_LOSS_ONLY 2
+/*               OKGE_TRAIN_UNIQUE_CANDIDATES -- cand->ids names every entity at most once (true for the lists
+ *               okge_collate_batch emits): their gradient rows are written without atomics.  Without the flag an
+ *               explicit id list may repeat entities (precompute_batch_shared_inputs takes any list). */
+#define OKGE_TRAIN_UNIQUE_CANDIDATES 4
 int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch,
                                 const okge_candidates *cand, const okge_positives *pos,
                                 int32_t loss_kind, float label_smoothing, double normalizer, int32_t flags,
@@ -213,6 +217,55 @@ int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr,
 /* The same update on two parameter tensors (entity and relation table) in ONE launch. */
 int okge_adagrad_step2(float *p0, float *g0, float *sum0, int64_t n0, float *p1, float *g1, float *sum1,
                        int64_t n1, float lr, float weight_decay, float eps, int32_t zero_grad, void *stream);
+
+/* ---- batch producer (HOST pointers; no device work) ---------------------------------------------------
+ * Replaces OneToNMentionRelationDataset_collate_func (dataset.py:724-940) and the packed answer-group decoding
+ * it uses (utils/misc.py:72-89).  The dataset is the reference's three int32 tensors (dataset.py:567-710):
+ *   prefixes [P][7] = a, b, this_start, this_end, all_start, all_end, slot   (slot 0: (rel, obj) = po prefix,
+ *                                                                             slot 2: (subj, rel) = sp prefix)
+ *   seen_entities       packed answer groups of this split: for k groups [b_0+L .. b_k+L, 0, ids...], L = k+2
+ *   all_splits_entities answers over train+valid+test (the evaluation filter)
+ * A batch = `rows` (indices into prefixes, in sampler order).  Output, in caller-allocated host buffers:
+ *   po_rel/po_obj [n_po], sp_subj/sp_rel [n_sp]   rows keep batch order within a slot, po rows come first
+ *   pos_col/pos_row [nnz]   the label tensor as unique coordinates sorted by (col, row) = okge_positives
+ *   cand_ids [n_cand]       batch-shared mode: answer ids in first-seen order (training: this split's answers,
+ *                           evaluation: all splits'), filled up to min_size_batch_labels with entities sampled
+ *                           without replacement (seen ones removed).  DIVERGENCE: the reference appends the
+ *                           numpy-sampled fill-up ids in the iteration order of a Python set; here a
+ *                           splitmix64(seed) stream in sampling order.  1-vs-all mode: ids offset..n_entities-1,
+ *                           not written.
+ *   row_ptr/grp_ptr/ids, filt_ptr/filt_col   evaluation only: label_ids and filter_mask as okge_filtered_ranks takes
+ *   normalizer_loss = B*N (dataset.py:935), normalizer_metric = nnz (dataset.py:934).
+ * Returns OKGE_ERR_WORKSPACE (sizes needed are then in the descriptor) if a capacity is too small. */
+typedef struct okge_prefix_table {
+    const int32_t *prefixes;
+    int64_t n_prefixes;
+    const int32_t *seen_entities;
+    int64_t n_seen;
+    const int32_t *all_splits_entities;
+    int64_t n_all;
+    int32_t n_entities;      /* entity vocabulary size incl. the reserved ids */
+    int32_t entity_offset;   /* first real entity id (2) */
+} okge_prefix_table;
+
+typedef struct okge_collated {
+    int64_t cap_rows, cap_pos, cap_cand, cap_groups, cap_ids, cap_filter;   /* capacities, set by the caller */
+    int32_t *po_rel, *po_obj, *sp_subj, *sp_rel;                            /* [cap_rows] each */
+    int32_t *pos_row, *pos_col;                                             /* [cap_pos] */
+    int32_t *cand_ids;                                                      /* [cap_cand], batch-shared only */
+    int64_t *row_ptr;                                                       /* [cap_rows + 1], evaluation only */
+    int64_t *grp_ptr;                                                       /* [cap_groups + 1] */
+    int32_t *ids;                                                           /* [cap_ids] */
+    int64_t *filt_ptr;                                                      /* [cap_rows + 1] */
+    int32_t *filt_col;                                                      /* [cap_filter] */
+    int32_t n_po, n_sp;                                                     /* sizes, filled by the call */
+    int64_t nnz, n_cand, n_groups, n_ids, n_filter;
+    double normalizer_loss, normalizer_metric;
+} okge_collated;
+
+int okge_collate_batch(const okge_prefix_table *table, const int64_t *rows, int32_t B, int32_t is_training,
+                       int32_t use_batch_shared_entities, int32_t min_size_batch_labels, uint64_t seed,
+                       okge_collated *out);
 
 /* ---- filtered ranks ---------------------------------------------------------------------------------
  * Replaces OneToNMentionRelationDataset.compute_metrics' rank rule (dataset.py:423-446):

@@ -14,13 +14,14 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libokge_hip.so")
-SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_misc.hip"]
+SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_misc.hip", "okge_collate.cpp"]
 HEADERS = ["okge_device.h", "okge_kernels.h", os.path.join("..", "..", "include", "okge.h")]
 
 OKGE_COMPLEX, OKGE_DISTMULT = 0, 1
 OKGE_LOSS_BCE, OKGE_LOSS_KL = 0, 1
 OKGE_TRAIN_GRADS_ZERO = 1
 OKGE_TRAIN_LOSS_ONLY = 2
+OKGE_TRAIN_UNIQUE_CANDIDATES = 4
 SCORERS = {"complex": OKGE_COMPLEX, "distmult": OKGE_DISTMULT}
 LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 
@@ -28,7 +29,7 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
-           "okge_rank_counts", "okge_score_triples", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_rank_counts", "okge_score_triples", "okge_collate_batch", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -63,6 +64,21 @@ class Shard(Structure):
 
 class Positives(Structure):
     _fields_ = [("col", c_void_p), ("row", c_void_p), ("nnz", c_int32)]
+
+
+class PrefixTable(Structure):
+    _fields_ = [("prefixes", c_void_p), ("n_prefixes", c_int64), ("seen_entities", c_void_p), ("n_seen", c_int64),
+                ("all_splits_entities", c_void_p), ("n_all", c_int64), ("n_entities", c_int32), ("entity_offset", c_int32)]
+
+
+class Collated(Structure):
+    _fields_ = [("cap_rows", c_int64), ("cap_pos", c_int64), ("cap_cand", c_int64), ("cap_groups", c_int64),
+                ("cap_ids", c_int64), ("cap_filter", c_int64),
+                ("po_rel", c_void_p), ("po_obj", c_void_p), ("sp_subj", c_void_p), ("sp_rel", c_void_p),
+                ("pos_row", c_void_p), ("pos_col", c_void_p), ("cand_ids", c_void_p), ("row_ptr", c_void_p),
+                ("grp_ptr", c_void_p), ("ids", c_void_p), ("filt_ptr", c_void_p), ("filt_col", c_void_p),
+                ("n_po", c_int32), ("n_sp", c_int32), ("nnz", c_int64), ("n_cand", c_int64), ("n_groups", c_int64),
+                ("n_ids", c_int64), ("n_filter", c_int64), ("normalizer_loss", c_double), ("normalizer_metric", c_double)]
 
 
 def needs_build():
@@ -138,6 +154,9 @@ def lib():
     L.okge_score_triples.restype = c_int32
     L.okge_score_triples.argtypes = [c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32,
                                      c_void_p, c_void_p]
+    L.okge_collate_batch.restype = c_int32
+    L.okge_collate_batch.argtypes = [POINTER(PrefixTable), c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint64,
+                                     POINTER(Collated)]
     L.okge_scale_inplace.restype = c_int32
     L.okge_scale_inplace.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.okge_adagrad_step.restype = c_int32

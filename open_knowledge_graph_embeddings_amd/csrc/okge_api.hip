@@ -202,6 +202,8 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
 
 }  // namespace
 
+int okge::report_error(int code, const std::string &msg) { return fail(code, msg); }
+
 extern "C" {
 
 int okge_abi_version(void) { return OKGE_ABI_VERSION; }
@@ -291,6 +293,9 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     a.pos_col = pos->col; a.pos_row = pos->row; a.nnz = pos->nnz;
     a.tile_ptr = reinterpret_cast<const int32_t *>(ws + g.off_tptr);
     a.grads_zero = (flags & OKGE_TRAIN_GRADS_ZERO) ? 1 : 0;
+    // an explicit id list may name an entity twice (precompute_batch_shared_inputs takes any list): its rows are then
+    // accumulated with atomics unless the caller vouches for uniqueness (the collator's lists are unique)
+    a.cand_exclusive = (!cand->ids || (flags & OKGE_TRAIN_UNIQUE_CANDIDATES)) ? 1 : 0;
     a.loss_only = loss_only ? 1 : 0;
     a.G = reinterpret_cast<float *>(ws + g.off_GT);
     a.Cm = reinterpret_cast<float *>(ws + g.off_Cm);

@@ -1,5 +1,6 @@
 // Kernel argument blocks and launcher prototypes shared by the .hip translation units.
 #pragma once
+#include <string>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "okge_device.h"
@@ -32,7 +33,7 @@ struct FusedArgs {
     unsigned long long *stamps_dbg;   // diagnostic build (-DOKGE_STAMPS) only
     int64_t        ldx;
     DropDev        drop_c;
-    int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero;
+    int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero, cand_exclusive;
     float          y_pos, y_neg, inv_norm;
     int32_t        cand_col0;  // global column (candidate position) of local candidate 0: positives, dropout keys
     int32_t        loss_only;  // forward + loss only: no G store, no dC product, no write-back
@@ -76,6 +77,9 @@ hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, f
                           hipStream_t st);
 hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p1, float *g1, float *s1, int64_t n1,
                            float lr, float wd, float eps, int zero_grad, hipStream_t st);
+// error text for okge_last_error(), shared by the translation units of the C ABI (defined in okge_api.hip)
+int report_error(int code, const std::string &msg);
+
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         if (!a.loss_only && n < a.N) {
             const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
             float *drow = a.dE + cid * d;
-            const bool exclusive = gridDim.y == 1;
+            const bool exclusive = gridDim.y == 1 && a.cand_exclusive;    // one workgroup per entity row: plain stores
 #pragma unroll
             for (int it = 0; it < NOIT; ++it) {
                 const int o = q8 + 8 * it, k = 8 * o;

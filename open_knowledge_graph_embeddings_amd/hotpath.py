@@ -58,6 +58,7 @@ class PrefixBatch:
     cand_first: int = 2
     n_cand: int = 0
     cand_table: Optional[torch.Tensor] = None  # scoring only: gather candidates from this (rows, d) table, not E
+    cand_unique: bool = False               # cand_ids names every entity at most once (the collator's lists do)
     drop_po_ent: DropoutSpec = field(default_factory=DropoutSpec)
     drop_po_rel: DropoutSpec = field(default_factory=DropoutSpec)
     drop_sp_ent: DropoutSpec = field(default_factory=DropoutSpec)
@@ -203,7 +204,8 @@ class HotPath:
         N.check(self.lib.okge_train_forward_backward(
             ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), ctypes.byref(pos),
             N.LOSSES[loss] if isinstance(loss, str) else int(loss), float(label_smoothing), float(normalizer),
-            (N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0) | (N.OKGE_TRAIN_LOSS_ONLY if loss_only else 0),
+            (N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0) | (N.OKGE_TRAIN_LOSS_ONLY if loss_only else 0) |
+            (N.OKGE_TRAIN_UNIQUE_CANDIDATES if batch.cand_unique else 0),
             loss_out.data_ptr(), _ptr(dE), _ptr(dR),
             None if scores is None else scores.data_ptr(), 0 if scores is None else scores.stride(0),
             ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_forward_backward")

@@ -1,0 +1,189 @@
+"""Batch producer: the host-side C-ABI collator (csrc/okge_collate.cpp) through
+open_knowledge_graph_embeddings_amd.dataset.OneToNBatchProducer against the reference's own collate outputs
+(tests/golden/g4_collate_toy.npz, 32 cases) and against the oracle restatement on random tables.  Host code only:
+runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import kge_oracle as ko
+
+
+def producer(z, training, shared, min_size, **kw):
+    from open_knowledge_graph_embeddings_amd.dataset import OneToNBatchProducer
+    return OneToNBatchProducer(z["prefixes"], z["seen"], z["all_splits"], int(z["n_ent"]), int(z["offset"]),
+                               is_training_data=training, use_batch_shared_entities=shared,
+                               min_size_batch_labels=min_size, device="cpu", **kw)
+
+
+def cases():
+    z = golden("g4_collate_toy")
+    for c in range(int(z["n_cases"])):
+        t = f"c{c}_"
+        shared, min_size, training = (int(x) for x in z[t + "cfg"])
+        yield z, t, bool(shared), min_size, bool(training)
+
+
+def coords(b):
+    """(row, col) label pairs in row-major order, like label_tensor.nonzero()"""
+    rc = np.stack([b.pos_row.numpy(), b.pos_col.numpy()], axis=1)
+    return rc[np.lexsort((rc[:, 1], rc[:, 0]))]
+
+
+def test_collate_matches_reference_cases(okge_lib):
+    n = 0
+    for z, t, shared, min_size, training in cases():
+        out = producer(z, training, shared, min_size).collate(z[t + "rows"], seed=3)
+        b = out.batch
+        ref_cand = z[t + "cand"]
+        if shared:
+            n_seen = len(ko.collate_batch(z["prefixes"][z[t + "rows"]], z["seen"], z["all_splits"], int(z["n_ent"]),
+                                          int(z["offset"]), training, True, 0)["cand"])
+            got = b.cand_ids.numpy()
+            assert len(got) == len(ref_cand)
+            np.testing.assert_array_equal(got[:n_seen], ref_cand[:n_seen])       # first-seen order of the answers
+            fill = got[n_seen:]                                                  # sampled fill-up: order is ours
+            assert len(set(fill.tolist())) == len(fill) and not set(fill.tolist()) & set(got[:n_seen].tolist())
+            assert fill.size == 0 or (fill.min() >= int(z["offset"]) and fill.max() < int(z["n_ent"]))
+        else:
+            assert b.cand_ids is None and b.cand_first == int(z["offset"]) and out.n_cand == len(ref_cand)
+        for name, cols in (("po", (b.po_rel, b.po_obj)), ("sp", (b.sp_subj, b.sp_rel))):
+            got = np.zeros((0, 2), np.int32) if cols[0] is None else np.stack([c.numpy() for c in cols], axis=1)
+            np.testing.assert_array_equal(got, z[t + name])
+        np.testing.assert_array_equal(coords(b), z[t + "labels"])
+        col = b.pos_col.numpy()
+        assert (np.diff(col) >= 0).all()                                         # okge_positives: sorted by column
+        assert [out.normalizer_loss, out.normalizer_metric] == z[t + "norm"].tolist()
+        assert (b.B, out.n_cand) == tuple(z[t + "shape"])
+        np.testing.assert_array_equal(out.dense_labels().nonzero().numpy(), z[t + "labels"])
+        if training:
+            assert out.row_ptr is None and out.filt_ptr is None
+        else:
+            np.testing.assert_array_equal(out.row_ptr.numpy(), z[t + "row_ptr"])
+            np.testing.assert_array_equal(out.grp_ptr.numpy(), z[t + "grp_ptr"])
+            np.testing.assert_array_equal(out.ids.numpy(), z[t + "ids"])
+            fp, fc = out.filt_ptr.numpy(), out.filt_col.numpy()
+            filt = np.stack([np.repeat(np.arange(b.B), np.diff(fp)), fc], axis=1).astype(np.int32)
+            np.testing.assert_array_equal(filt, z[t + "filter"])
+        n += 1
+    assert n == 32
+
+
+def random_tables(rng, n_ent, n_prefix, max_groups=6, max_mentions=3):
+    from open_knowledge_graph_embeddings_amd.dataset import pack_groups
+    seen, allsp, rows = [], [], []
+    for _ in range(n_prefix):
+        groups = [rng.integers(2, n_ent, size=int(rng.integers(1, max_mentions + 1))).tolist()
+                  for _ in range(int(rng.integers(1, max_groups + 1)))]
+        packed = pack_groups(groups).tolist()
+        assert packed == ko.pack_groups(groups)
+        everything = list(dict.fromkeys([e for g in groups for e in g] + rng.integers(2, n_ent, size=5).tolist()))
+        slot, rel, ent = int(rng.choice([0, 2])), int(rng.integers(2, 50)), int(rng.integers(2, n_ent))
+        rows.append([rel if slot == 0 else ent, ent if slot == 0 else rel, len(seen), len(seen) + len(packed),
+                     len(allsp), len(allsp) + len(everything), slot])          # slot 0: (rel, obj), slot 2: (subj, rel)
+        seen += packed
+        allsp += everything
+    return dict(prefixes=np.asarray(rows, np.int32), seen=np.asarray(seen, np.int32),
+                all_splits=np.asarray(allsp, np.int32), n_ent=n_ent, offset=2)
+
+
+@pytest.mark.parametrize("shared,training", [(False, True), (False, False), (True, True), (True, False)])
+def test_collate_matches_oracle_random(okge_lib, shared, training):
+    rng = np.random.default_rng(5 + 2 * shared + training)
+    z = random_tables(rng, 5000, 700)
+    p = producer(z, training, shared, 0)
+    for _ in range(5):
+        rows = rng.choice(700, size=int(rng.integers(1, 257)), replace=False)
+        out = p.collate(rows)
+        ref = ko.collate_batch(z["prefixes"][rows], z["seen"], z["all_splits"], 5000, 2, training, shared, 0)
+        np.testing.assert_array_equal(coords(out.batch), np.asarray(ref["labels"], np.int32).reshape(-1, 2))
+        if shared:
+            np.testing.assert_array_equal(out.batch.cand_ids.numpy(), ref["cand"])
+        if not training:
+            ids = [i for row in ref["groups"] for g in row for i in g]
+            np.testing.assert_array_equal(out.ids.numpy(), np.asarray(ids, np.int32))
+            np.testing.assert_array_equal(out.filt_col.numpy(), np.asarray([c for f in ref["filters"] for c in f], np.int32))
+            np.testing.assert_array_equal(np.diff(out.filt_ptr.numpy()), [len(f) for f in ref["filters"]])
+            np.testing.assert_array_equal(np.diff(out.row_ptr.numpy()), [len(r) for r in ref["groups"]])
+
+
+def test_fill_up_negatives(okge_lib):
+    z = random_tables(np.random.default_rng(9), 3000, 64)
+    p = producer(z, True, True, 1024)
+    a, b2, c = p.collate(np.arange(32), seed=1), p.collate(np.arange(32), seed=1), p.collate(np.arange(32), seed=2)
+    ids = a.batch.cand_ids.numpy()
+    assert len(ids) == 1024 == len(set(ids.tolist())) and ids.min() >= 2 and ids.max() < 3000
+    np.testing.assert_array_equal(ids, b2.batch.cand_ids.numpy())                # same seed, same list
+    assert (ids != c.batch.cand_ids.numpy()).any()
+    assert a.normalizer_loss == 32 * 1024
+
+
+def test_epoch_iteration_and_errors(okge_lib):
+    from open_knowledge_graph_embeddings_amd import OkgeError
+    z = random_tables(np.random.default_rng(11), 400, 103)
+    p = producer(z, True, False, 0, batch_size=16, shuffle=True, seed=5)
+    seen_rows = 0
+    batches = list(p)
+    assert len(batches) == len(p) == 103 // 16
+    for cb in batches:
+        seen_rows += cb.batch.B
+        assert cb.normalizer_loss == 16 * 398 and cb.batch.nnz == cb.normalizer_metric
+    assert seen_rows == 96
+    first = [b.batch.po_rel.tolist() if b.batch.po_rel is not None else [] for b in batches]
+    again = [b.batch.po_rel.tolist() if b.batch.po_rel is not None else [] for b in p]          # next epoch reshuffles
+    assert first != again
+    assert len(list(producer(z, True, False, 0, batch_size=16, drop_last=False))) == 7
+    with pytest.raises(OkgeError):
+        p.collate(np.asarray([1000]))                                             # row outside the table
+    bad = dict(z)
+    bad["seen"] = z["seen"].copy()
+    bad["seen"][z["prefixes"][0, 2]] += 1                                         # corrupt a packed header
+    with pytest.raises(OkgeError):
+        producer(bad, True, False, 0).collate(np.asarray([0]))
+
+
+# --------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [False, True])
+def test_producer_feeds_train_step_and_ranks(okge_lib, shared):
+    """prefix table -> producer (pinned arena, one H2D copy) -> fused step / score + filtered ranks, against the
+    oracle fed with the dense tensors the reference's collate would have built."""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+    rng = np.random.default_rng(21)
+    n_ent, n_rel, d = 900, 50, 32
+    z = random_tables(rng, n_ent, 200)
+    E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal((n_rel, d)) * 0.3).astype(np.float32)
+    # training batches
+    p = producer(z, True, shared, 256 if shared else 0, batch_size=64)
+    p.device = torch.device("cuda:0")
+    st = FusedTrainStep(torch.from_numpy(E.copy()).cuda(), torch.from_numpy(R.copy()).cuda(), "complex", lr=0.3)
+    Eo, Ro, sE, sR = E.copy(), R.copy(), np.zeros_like(E), np.zeros_like(R)
+    for cb in p:
+        b = cb.batch
+        loss = float(st.step(b, normalizer=cb.normalizer_loss)[0])
+        cand = b.cand_ids.cpu().numpy() if shared else np.arange(2, n_ent)
+        out = ko.step_forward_backward(ko.COMPLEX, Eo, Ro, (b.po_rel.cpu().numpy(), b.po_obj.cpu().numpy()),
+                                       (b.sp_subj.cpu().numpy(), b.sp_rel.cpu().numpy()), cand,
+                                       cb.dense_labels().cpu().numpy(), normalizer=cb.normalizer_loss)
+        ko.adagrad_step(Eo, out["dE"], sE, 0.3)
+        ko.adagrad_step(Ro, out["dR"], sR, 0.3)
+        assert abs(loss - out["loss"]) <= 3e-5 * abs(out["loss"])
+    close = np.isclose(st.E.cpu().numpy(), Eo, rtol=1e-3, atol=1e-4)
+    assert close.mean() > 0.999
+    # evaluation batch
+    pe = producer(z, False, shared, 0, batch_size=48)
+    pe.device = torch.device("cuda:0")
+    cb = next(iter(pe))
+    b = cb.batch
+    hp = H.HotPath("cuda:0")
+    Et, Rt = torch.from_numpy(E).cuda(), torch.from_numpy(R).cuda()
+    x = hp.score(Et, Rt, "complex", b)
+    ranks = hp.filtered_ranks(x, cb.filt_ptr, cb.filt_col, cb.row_ptr, cb.grp_ptr, cb.ids).cpu().numpy()
+    filt = np.zeros((b.B, cb.n_cand), bool)
+    fp, fc = cb.filt_ptr.cpu().numpy(), cb.filt_col.cpu().numpy()
+    filt[np.repeat(np.arange(b.B), np.diff(fp)), fc] = True
+    ref = ko.filtered_ranks(x.cpu().numpy(), filt, cb.row_ptr.cpu().numpy(), cb.grp_ptr.cpu().numpy(), cb.ids.cpu().numpy())
+    np.testing.assert_array_equal(ranks, ref)

@@ -260,6 +260,35 @@ def test_random_vs_oracle(hp, case):
         np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=3e-5 * np.abs(r).max() + 1e-12)
 
 
+@pytest.mark.parametrize("grads_zero", [False, True])
+def test_repeated_candidate_ids_accumulate(hp, grads_zero):
+    """An explicit candidate list may name an entity several times (precompute_batch_shared_inputs takes any id
+    list, model.py:76-77): autograd's embedding backward sums the rows' gradients, so must the tile write-back --
+    across workgroups and inside one tile, with and without the zeroed-gradients fast path."""
+    E, R, z, _, _ = random_problem(77, 300, 9, 200, 40, 33)
+    rng = np.random.default_rng(78)
+    cand = rng.integers(2, 60, 700).astype(np.int32)                 # ~12 copies of each of 58 entities
+    y = np.zeros((73, 700), np.float32)
+    for b in range(73):
+        y[b, rng.choice(700, size=3, replace=False)] = 1
+    ref = oracle_step("complex", E, R, z, cand, y)
+    Et, Rt = dev(E), dev(R)
+    batch = make_batch(z, cand, 300, labels=y)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = hp.forward_backward(Et, Rt, "complex", batch, dE, dR, grads_zero=grads_zero)
+    assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+    for mine, r in ((dE, ref["dE"]), (dR, ref["dR"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=3e-5 * np.abs(r).max() + 1e-12)
+    # a list without repeats may be declared so (the collator's lists): plain stores, same numbers
+    E2, R2, z2, cand2, y2 = random_problem(79, 300, 9, 200, 40, 33, n_cand=250)
+    ref2 = oracle_step("complex", E2, R2, z2, cand2, y2)
+    batch2 = make_batch(z2, cand2, 300, labels=y2)
+    batch2.cand_unique = True
+    dE2, dR2 = torch.zeros_like(Et), torch.zeros_like(Rt)
+    hp.forward_backward(dev(E2), dev(R2), "complex", batch2, dE2, dR2, grads_zero=grads_zero)
+    np.testing.assert_allclose(dE2.cpu().numpy(), ref2["dE"], rtol=0, atol=3e-5 * np.abs(ref2["dE"]).max())
+
+
 def test_b_split_path(hp, monkeypatch):
     """Few candidate tiles -> the batch is split across blockIdx.y and dC goes through atomics."""
     E, R, z, cand, y = random_problem(5, 300, 11, 64, 200, 184, 100)
