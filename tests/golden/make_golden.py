@@ -21,6 +21,8 @@ Vectors:
   g4_collate_*    OneToNMentionRelationDataset_collate_func on packed toy prefix tables: 1-vs-all and batch-shared,
                   training and evaluation, with and without numpy-sampled fill-up negatives
   g5_ranks_*      OneToNMentionRelationDataset.compute_metrics (known answer + ties + mention groups)
+  g8_checkpoint   the checkpoint dict Trainer.save writes (state_dict + OptimRegime.state_dict()) after two steps,
+                  stored with torch.save (tensors / containers only), plus the third step's batch and result
   g7_traj_*       20 training steps, fixed batches -> loss curve and final tables
 """
 import os
@@ -433,9 +435,53 @@ def g4():
     save("g4_collate_toy", **kw)
 
 
+# ----------------------------------------------------------------------------------------------
+# G8: checkpoint interop (Trainer.save layout, trainer.py:608-618)
+# ----------------------------------------------------------------------------------------------
+def g8():
+    n_ent, n_rel, d, b = 90, 11, 24, 10
+    rng = np.random.default_rng(88)
+    m = make_model("LookupComplexRelationModel", n_ent, n_rel, d, seed=88)
+    m.train()
+    args = {"optimization_config": {"optimizer": "Adagrad", "epoch": 0, "lr": 0.3, "weight_decay": 1.0e-10},
+            "lr_scheduler_config": None}
+    opts = OptimRegime.setup_optimizer_regime(args=args, model=m)
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+    mod.train()
+    cand = torch.arange(n_ent)[2:].int().unsqueeze(1)
+    N = cand.shape[0]
+    kw = {}
+    for step in range(3):
+        po = (rand_ids(rng, 2, n_rel, b), rand_ids(rng, 2, n_ent, b))
+        sp = (rand_ids(rng, 2, n_ent, b), rand_ids(rng, 2, n_rel, b))
+        y = dense_labels(rng, 2 * b, N)
+        if step == 2:
+            # exactly what Trainer.save stores (minus the ResultsLog object, which is not tensor data)
+            state = {"epoch": 1, "training_steps": 2, "state_dict": m.state_dict(),
+                     "optimizer_state_dict": [o.state_dict() for o in opts], "validation_results": None}
+            torch.save(state, os.path.join(OUT, "g8_checkpoint.pt"))
+            kw.update(po_rel=npy(po[0]), po_obj=npy(po[1]), sp_subj=npy(sp[0]), sp_rel=npy(sp[1]), labels=y)
+        for o in opts:
+            o.update(1, step + 1)
+            o.zero_grad()
+        loss, _, _ = mod(inputs=[po, sp], labels=torch.from_numpy(y.copy()), use_batch_shared_entities=False,
+                         batch_shared_entities=cand, epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+        (loss.sum() / float(2 * b * N)).backward()
+        for o in opts:
+            o.step()
+    st = opts[0].optimizer.state
+    kw.update(loss=np.float64(loss.item()), E=npy(m.entity_embedding.weight), R=npy(m.relation_embedding.weight),
+              sumE=npy(st[m.entity_embedding.weight]["sum"]), sumR=npy(st[m.relation_embedding.weight]["sum"]))
+    save("g8_checkpoint_step3", **kw)
+    # the state after step 3, as the reference would save it: target layout for OUR writer
+    state = {"epoch": 1, "training_steps": 3, "state_dict": m.state_dict(),
+             "optimizer_state_dict": [o.state_dict() for o in opts], "validation_results": None}
+    torch.save(state, os.path.join(OUT, "g8_checkpoint_after.pt"))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g7):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g7, g8):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)
