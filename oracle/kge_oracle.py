@@ -351,6 +351,68 @@ def collate_batch(rows, seen_entities, all_splits_entities, n_entities, entity_o
 
 
 # ------------------------------------------------------------------------------------------------
+# on-disk format -> dataset tensors        openkge/dataset.py:480-710
+# 5-column TSV  s \t p \t o \t subject-mention-ids \t object-mention-ids   (utils/map_dataset_to_ids.py:11-17)
+# ------------------------------------------------------------------------------------------------
+DIRECTIONS = {          # name: (key column 2, key column 1, prefix columns, slot, answer column)  dataset.py:489-492
+    "sp_o": (1, 0, (0, 1), 2, 4),
+    "po_s": (1, 2, (1, 2), 0, 3),
+}
+
+
+def collect_prefix_groups(lines, direction):
+    """dataset.py:494-518.  Lines are sorted by the STRING of the relation column, then (stably) by the STRING of
+    the prefix entity column; consecutive lines with the same prefix form one record whose answer groups are the
+    mention-id lists of the answer column.  The record still open when the input ends is never written
+    (there is no flush after the loop): the last prefix in sort order is dropped."""
+    pref_p, pref_e, (c1, c2), slot, ans = DIRECTIONS[direction]
+    rows = [ln.split("\t") for ln in lines]
+    rows = sorted(sorted(rows, key=lambda f: f[pref_p]), key=lambda f: f[pref_e])
+    out, cur = [], None
+    for f in rows:
+        prefix = (int(f[c1]), int(f[c2]))
+        group = [int(i) for i in f[ans].split()]
+        if cur is not None and cur["prefix"] == prefix:
+            cur["entities"].append(group)
+        else:
+            if cur is not None:
+                out.append(cur)
+            cur = {"prefix": prefix, "entities": [group], "slot": slot}
+    return out
+
+
+def merge_all_splits(train, valid, test):
+    """dataset.py:520-565: records of the three splits, stably sorted by prefix (numeric), answers united per
+    prefix.  The reference keeps each union in a Python set's iteration order; here ascending."""
+    merged = {}
+    for rec in sorted(train + valid + test, key=lambda r: r["prefix"]):
+        merged.setdefault(rec["prefix"], set()).update(e for g in rec["entities"] for e in g)
+    return [(p, sorted(v)) for p, v in merged.items()]
+
+
+def dataset_tensors(records, merged, is_training, max_size_prefix_label=-1):
+    """dataset.py:567-710.  records / merged: {"sp_o": [...], "po_s": [...]} of one split / of all splits.
+    -> (seen_prefixes (P,7) int32, seen_entities int32, all_splits_entities int32)."""
+    all_ents, coords = [], {}
+    for d in ("sp_o", "po_s"):
+        for prefix, ents in merged[d]:
+            coords[(d, prefix)] = (len(all_ents), len(all_ents) + len(ents))
+            all_ents.extend(ents)
+    prefixes, seen = [], []
+    for d in ("sp_o", "po_s"):
+        for rec in records[d]:
+            groups = rec["entities"]
+            chunked = is_training and max_size_prefix_label > 1 and len(groups) > max_size_prefix_label
+            step = max_size_prefix_label if chunked else max(1, len(groups))
+            for off in range(0, len(groups), step):
+                packed = pack_groups(groups[off:off + step])
+                a, b = (0, 0) if is_training else coords[(d, rec["prefix"])]
+                prefixes.append([rec["prefix"][0], rec["prefix"][1], len(seen), len(seen) + len(packed), a, b, rec["slot"]])
+                seen.extend(packed)
+    return (np.asarray(prefixes, np.int32).reshape(-1, 7), np.asarray(seen, np.int32), np.asarray(all_ents, np.int32))
+
+
+# ------------------------------------------------------------------------------------------------
 # counter-based dropout masks (this build's replacement for torch's bernoulli_, SURVEY.md 'hard
 # parts'): Philox4x32-10, key = seed, counter = (row, column/8, stream, step).  Integer work ->
 # the HIP kernels reproduce these masks bit for bit.

@@ -20,6 +20,9 @@ Vectors:
   g3_adagrad_*    three optimisation steps through utils.optim.OptimRegime (Adagrad, leaked eps)
   g4_collate_*    OneToNMentionRelationDataset_collate_func on packed toy prefix tables: 1-vs-all and batch-shared,
                   training and evaluation, with and without numpy-sampled fill-up negatives
+  g6_dataset_*    OneToNMentionRelationDataset on tests/golden/toy_kg (our own synthetic 5-column TSV + id maps):
+                  seen_prefixes (P,7) / packed seen_entities / all_splits_entities for train, valid, test; plus
+                  shapes + sha256 of the same tensors for the reference's FB15k-237 valid/test files
   g5_ranks_*      OneToNMentionRelationDataset.compute_metrics (known answer + ties + mention groups)
   g8_checkpoint   the checkpoint dict Trainer.save writes (state_dict + OptimRegime.state_dict()) after two steps,
                   stored with torch.save (tensors / containers only), plus the third step's batch and result
@@ -436,6 +439,68 @@ def g4():
 
 
 # ----------------------------------------------------------------------------------------------
+# G6: on-disk formats -> dataset tensors
+# ----------------------------------------------------------------------------------------------
+def build_datasets(src_dir, files, max_size_prefix_label=-1):
+    import hashlib
+    import shutil
+    import tempfile
+    scratch = tempfile.mkdtemp(prefix="okge_g6_")
+    for f in os.listdir(src_dir):
+        if f.endswith(".txt"):
+            shutil.copy(os.path.join(src_dir, f), scratch)
+    out = {}
+    try:
+        ds = {}
+        for split, fname in files.items():
+            ds[split] = OneToNMentionRelationDataset(
+                dataset_dir=scratch, input_file=fname, is_training_data=(split == "train"), batch_size=8,
+                copy_data_to_dev_shm=False, max_size_prefix_label=max_size_prefix_label,
+                entity_id_tokens_ids_map_file="absent.txt", relation_id_tokens_ids_map_file="absent.txt")
+        ds["valid"].merge_all_splits_triples(dataset_dir=scratch, train_input_file=files["train"],
+                                             valid_input_file=files["valid"], test_input_file=files["test"])
+        for split in ds:
+            ds[split].create_data_tensors(dataset_dir=scratch, train_input_file=files["train"],
+                                          valid_input_file=files["valid"], test_input_file=files["test"])
+            out[split] = (npy(ds[split].seen_prefixes_tensor), npy(ds[split].seen_entities_tensor),
+                          npy(ds[split].all_splits_entities_tensor), ds[split].entity_vocab_size)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    return out
+
+
+def g6():
+    import hashlib
+    toy = os.path.join(OUT, "toy_kg")
+    files = {"train": "train.txt", "valid": "valid.txt", "test": "test.txt"}
+    kw = {}
+    for split, (pref, seen, allsp, n_ent) in build_datasets(toy, files).items():
+        kw.update({f"{split}_prefixes": pref, f"{split}_seen": seen, f"{split}_all": allsp})
+        kw["entity_vocab_size"] = np.int64(n_ent)
+    # training split with max_size_prefix_label = 3: long answer lists are cut into several prefix rows.  The
+    # reference over-allocates these tensors (its counting loop runs one chunk too far, dataset.py:628-640) and
+    # leaves the tail uninitialised; consumers of this fixture compare only the rows / ids they produce themselves.
+    pref, seen, _, _ = build_datasets(toy, files, max_size_prefix_label=3)["train"]
+    kw.update(train3_prefixes=pref, train3_seen=seen)
+    save("g6_dataset_toy", **kw)
+    # FB15k-237 as shipped with the reference (train split absent: test.txt stands in for it); hashes only
+    fb = "/root/reference/data/fb15k237/mapped_to_ids"
+    kw = {}
+    for split, (pref, seen, allsp, n_ent) in build_datasets(fb, {"train": "test.txt", "valid": "valid.txt", "test": "test.txt"}).items():
+        if split != "valid":       # "test" shares its tensor cache file with the stand-in training split: skip
+            continue
+        sort_slices = np.concatenate([np.sort(allsp[a:b]) for a, b in sorted({(int(r[4]), int(r[5])) for r in pref})]) if len(pref) else allsp
+        kw.update({f"{split}_shapes": np.asarray([pref.shape[0], seen.shape[0], allsp.shape[0]], np.int64),
+                   f"{split}_sha_prefixes": hashlib.sha256(np.ascontiguousarray(pref).tobytes()).hexdigest(),
+                   f"{split}_sha_seen": hashlib.sha256(np.ascontiguousarray(seen).tobytes()).hexdigest(),
+                   # the order inside one prefix's all-splits slice is a Python set's iteration order: hash the
+                   # slices sorted (each distinct slice once, in table order)
+                   f"{split}_sha_all_sorted": hashlib.sha256(np.ascontiguousarray(sort_slices).tobytes()).hexdigest()})
+        kw["entity_vocab_size"] = np.int64(n_ent)
+    save("g6_dataset_fb15k237_hashes", **kw)
+
+
+# ----------------------------------------------------------------------------------------------
 # G8: checkpoint interop (Trainer.save layout, trainer.py:608-618)
 # ----------------------------------------------------------------------------------------------
 def g8():
@@ -481,7 +546,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g7, g8):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)

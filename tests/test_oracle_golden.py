@@ -311,3 +311,35 @@ def test_g4_collate_oracle_matches_reference():
             np.testing.assert_array_equal(np.asarray(ids, np.int32), z[t + "ids"])
         n += 1
     assert n == 32
+
+
+# ---------------------------------------------------------------------------------------------- G6
+def toy_records():
+    import os
+    from conftest import GOLDEN
+    lines = {sp: open(os.path.join(GOLDEN, "toy_kg", sp + ".txt")).readlines() for sp in ("train", "valid", "test")}
+    rec = {sp: {d: ko.collect_prefix_groups(lines[sp], d) for d in ko.DIRECTIONS} for sp in lines}
+    merged = {d: ko.merge_all_splits(rec["train"][d], rec["valid"][d], rec["test"][d]) for d in ko.DIRECTIONS}
+    return rec, merged
+
+
+def assert_all_splits_equal(pref, mine, ref):
+    """same slices; inside a slice the reference keeps a Python set's iteration order"""
+    assert mine.shape == ref.shape
+    for a, b in {(int(r[4]), int(r[5])) for r in pref}:
+        np.testing.assert_array_equal(np.sort(mine[a:b]), np.sort(ref[a:b]))
+
+
+def test_g6_dataset_tensors_oracle_matches_reference():
+    z = golden("g6_dataset_toy")
+    rec, merged = toy_records()
+    for split in ("train", "valid", "test"):
+        pref, seen, allsp = ko.dataset_tensors(rec[split], merged, split == "train")
+        np.testing.assert_array_equal(pref, z[split + "_prefixes"])
+        np.testing.assert_array_equal(seen, z[split + "_seen"])
+        assert_all_splits_equal(z["valid_prefixes"], allsp, z[split + "_all"])
+    # max_size_prefix_label = 3: the reference's tensors carry an uninitialised tail (over-counted allocation)
+    pref, seen, _ = ko.dataset_tensors(rec["train"], merged, True, max_size_prefix_label=3)
+    assert 0 < len(pref) <= len(z["train3_prefixes"]) and len(seen) <= len(z["train3_seen"])
+    np.testing.assert_array_equal(pref, z["train3_prefixes"][:len(pref)])
+    np.testing.assert_array_equal(seen, z["train3_seen"][:len(seen)])
