@@ -267,6 +267,24 @@ int okge_collate_batch(const okge_prefix_table *table, const int64_t *rows, int3
                        int32_t use_batch_shared_entities, int32_t min_size_batch_labels, uint64_t seed,
                        okge_collated *out);
 
+/* ---- dataset loader (HOST; text files -> the tensors okge_collate_batch reads) --------------------------
+ * Replaces OneToNMentionRelationDataset._collect_seen_triples / merge_all_splits_triples / create_data_tensors
+ * (dataset.py:480-710) for the 5-column id format  s \t p \t o \t subj-mention-ids \t obj-mention-ids
+ * (utils/map_dataset_to_ids.py:11-17), without the jsonl / pickle intermediates.  Split 0 = train (rows carry
+ * all_start = all_end = 0; answer lists longer than max_size_prefix_label > 1 are cut into several rows),
+ * 1 = valid, 2 = test.  Kept reference behaviour: string sort keys, the last prefix in sort order of every
+ * (file, direction) is dropped (dataset.py:501-518 never flushes it), sp_o rows before po_s rows.
+ * Divergences: ids inside one all-splits slice are ascending (reference: a Python set's iteration order);
+ * no uninitialised tail rows with max_size_prefix_label (dataset.py:628-640 over-allocates). */
+typedef struct okge_dataset okge_dataset;
+int okge_dataset_open(const char *train_path, const char *valid_path, const char *test_path,
+                      int32_t max_size_prefix_label, okge_dataset **out);
+int okge_dataset_sizes(const okge_dataset *ds, int32_t split, int64_t *n_prefixes, int64_t *n_seen, int64_t *n_all,
+                       int32_t *max_entity_id, int32_t *max_relation_id);
+int okge_dataset_copy(const okge_dataset *ds, int32_t split, int32_t *prefixes /* [P][7] */,
+                      int32_t *seen_entities, int32_t *all_splits_entities);   /* NULL pointers are skipped */
+void okge_dataset_close(okge_dataset *ds);
+
 /* ---- filtered ranks ---------------------------------------------------------------------------------
  * Replaces OneToNMentionRelationDataset.compute_metrics' rank rule (dataset.py:423-446):
  * for row b and each of its answer groups g: true = max_{j in g} scores[b][j];

@@ -190,3 +190,63 @@ class OneToNBatchProducer:
                 raise item
             yield self.to_device(*item)
         th.join()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# On-disk formats: text files -> dataset tensors through the C ABI's host-side loader
+# (csrc/okge_dataset.cpp), and the id-map files -> vocabulary sizes.
+# ------------------------------------------------------------------------------------------------------------------
+SPLITS = {"train": 0, "valid": 1, "test": 2}
+
+
+def load_dataset_tensors(dataset_dir, train_input_file="train.txt", valid_input_file="valid.txt",
+                         test_input_file="test.txt", max_size_prefix_label=-1):
+    """OneToNMentionRelationDataset._collect_seen_triples + merge_all_splits_triples + create_data_tensors
+    (dataset.py:480-710) in one call, no cache files written.
+    -> {"train"|"valid"|"test": (seen_prefixes (P,7) int32, seen_entities int32)}, all_splits_entities int32,
+       (max entity id, max relation id) seen in the files."""
+    import os
+    L = N.lib()
+    h = ctypes.c_void_p()
+    paths = [os.path.join(dataset_dir, f).encode() for f in (train_input_file, valid_input_file, test_input_file)]
+    N.check(L.okge_dataset_open(paths[0], paths[1], paths[2], int(max_size_prefix_label), ctypes.byref(h)),
+            "okge_dataset_open")
+    try:
+        out, all_splits, max_ids = {}, None, (0, 0)
+        for name, s in SPLITS.items():
+            n_p, n_s, n_a = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+            me, mr = ctypes.c_int32(), ctypes.c_int32()
+            N.check(L.okge_dataset_sizes(h, s, ctypes.byref(n_p), ctypes.byref(n_s), ctypes.byref(n_a), ctypes.byref(me),
+                                         ctypes.byref(mr)), "okge_dataset_sizes")
+            pref = np.empty((n_p.value, 7), np.int32)
+            seen = np.empty(n_s.value, np.int32)
+            if all_splits is None:
+                all_splits = np.empty(n_a.value, np.int32)
+            N.check(L.okge_dataset_copy(h, s, pref.ctypes.data, seen.ctypes.data, all_splits.ctypes.data if s == 0 else None),
+                    "okge_dataset_copy")
+            out[name] = (pref, seen)
+            max_ids = (me.value, mr.value)
+        return out, all_splits, max_ids
+    finally:
+        L.okge_dataset_close(h)
+
+
+def read_id_map_size(path):
+    """`*_id_map.txt` (`# token\\tid\\tcount`, ids start at 2; index_mapper.py:95-108): vocabulary size = max id + 1,
+    as EntityRelationDatasetBase.load_vocab computes it (dataset.py:172-184, :303-304)."""
+    size = -1
+    with open(path, encoding="utf-8") as f:
+        for i, line in enumerate(f):
+            if i == 0 and line.startswith("#"):
+                continue
+            parts = line.split("\t")
+            if len(parts) >= 2:
+                size = max(size, int(parts[1]))
+    return size + 1
+
+
+def dataset_meta(dataset_dir, entity_id_map_file="entity_id_map.txt", relation_id_map_file="relation_id_map.txt"):
+    """EntityRelationDatasetMeta with the sizes the lookup models read (get_dataset_meta_dict, dataset.py:127-142)."""
+    import os
+    return EntityRelationDatasetMeta(entities_size=read_id_map_size(os.path.join(dataset_dir, entity_id_map_file)),
+                                     relations_size=read_id_map_size(os.path.join(dataset_dir, relation_id_map_file)))

@@ -2,6 +2,8 @@
 open_knowledge_graph_embeddings_amd.dataset.OneToNBatchProducer against the reference's own collate outputs
 (tests/golden/g4_collate_toy.npz, 32 cases) and against the oracle restatement on random tables.  Host code only:
 runs without a GPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -187,3 +189,80 @@ def test_producer_feeds_train_step_and_ranks(okge_lib, shared):
     filt[np.repeat(np.arange(b.B), np.diff(fp)), fc] = True
     ref = ko.filtered_ranks(x.cpu().numpy(), filt, cb.row_ptr.cpu().numpy(), cb.grp_ptr.cpu().numpy(), cb.ids.cpu().numpy())
     np.testing.assert_array_equal(ranks, ref)
+
+
+# --------------------------------------------------------------------------------- on-disk format -> tensors (f3)
+def test_dataset_loader_matches_reference_tensors(okge_lib):
+    """csrc/okge_dataset.cpp on tests/golden/toy_kg against the tensors the reference's dataset class built from the
+    same files (tests/golden/g6_dataset_toy.npz), and against the oracle restatement."""
+    import os
+    from conftest import GOLDEN
+    from open_knowledge_graph_embeddings_amd.dataset import dataset_meta, load_dataset_tensors
+    from test_oracle_golden import assert_all_splits_equal, toy_records
+    z = golden("g6_dataset_toy")
+    toy = os.path.join(GOLDEN, "toy_kg")
+    out, all_splits, max_ids = load_dataset_tensors(toy)
+    for split in ("train", "valid", "test"):
+        np.testing.assert_array_equal(out[split][0], z[split + "_prefixes"])
+        np.testing.assert_array_equal(out[split][1], z[split + "_seen"])
+    assert_all_splits_equal(z["valid_prefixes"], all_splits, z["valid_all"])
+    meta = dataset_meta(toy)
+    assert meta.entities_size == int(z["entity_vocab_size"]) == 45 and meta.relations_size == 7
+    assert max_ids[0] < meta.entities_size and max_ids[1] < meta.relations_size
+    # long answer lists cut into several training rows
+    out3, _, _ = load_dataset_tensors(toy, max_size_prefix_label=3)
+    rec, merged = toy_records()
+    pref, seen, allsp = ko.dataset_tensors(rec["train"], merged, True, max_size_prefix_label=3)
+    np.testing.assert_array_equal(out3["train"][0], pref)
+    np.testing.assert_array_equal(out3["train"][1], seen)
+    np.testing.assert_array_equal(all_splits, allsp)                         # same (ascending) order as the oracle
+    np.testing.assert_array_equal(pref, z["train3_prefixes"][:len(pref)])    # reference: plus an uninitialised tail
+    np.testing.assert_array_equal(out3["valid"][0], out["valid"][0])
+
+
+def test_dataset_loader_fb15k237_hashes(okge_lib):
+    """The reference's own FB15k-237 files (present only where /root/reference is mounted; skipped elsewhere)."""
+    import hashlib
+    from open_knowledge_graph_embeddings_amd.dataset import load_dataset_tensors
+    fb = "/root/reference/data/fb15k237/mapped_to_ids"
+    if not os.path.isdir(fb):
+        pytest.skip("reference data not mounted")
+    z = golden("g6_dataset_fb15k237_hashes")
+    out, all_splits, _ = load_dataset_tensors(fb, train_input_file="test.txt")       # train split absent upstream
+    pref, seen = out["valid"]
+    assert [pref.shape[0], seen.shape[0], all_splits.shape[0]] == z["valid_shapes"].tolist() == [20110, 110356, 75998]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()    # noqa: E731
+    assert sha(pref) == str(z["valid_sha_prefixes"]) and sha(seen) == str(z["valid_sha_seen"])
+    slices = np.concatenate([np.sort(all_splits[a:b]) for a, b in sorted({(int(r[4]), int(r[5])) for r in pref})])
+    assert sha(slices) == str(z["valid_sha_all_sorted"])
+
+
+def test_dataset_loader_errors(okge_lib, tmp_path):
+    from open_knowledge_graph_embeddings_amd import OkgeError
+    from open_knowledge_graph_embeddings_amd.dataset import load_dataset_tensors
+    with pytest.raises(OkgeError):
+        load_dataset_tensors(str(tmp_path))                                            # files missing
+    for name in ("train.txt", "valid.txt", "test.txt"):
+        (tmp_path / name).write_text("2\t3\t4\t2\t4\n5\t3\n")
+    with pytest.raises(OkgeError):
+        load_dataset_tensors(str(tmp_path))                                            # a short line
+
+
+def test_files_to_batches_end_to_end(okge_lib):
+    """toy_kg text files -> loader -> producer -> batches, against the oracle fed with the reference-built tensors"""
+    import os
+    from conftest import GOLDEN
+    from open_knowledge_graph_embeddings_amd.dataset import OneToNBatchProducer, dataset_meta, load_dataset_tensors
+    toy = os.path.join(GOLDEN, "toy_kg")
+    z = golden("g6_dataset_toy")
+    out, all_splits, _ = load_dataset_tensors(toy)
+    meta = dataset_meta(toy)
+    p = OneToNBatchProducer(out["valid"][0], out["valid"][1], all_splits, meta.entities_size, batch_size=16,
+                            is_training_data=False, drop_last=False)
+    n = 0
+    for cb, rows in zip(p, p.batch_rows()):
+        ref = ko.collate_batch(z["valid_prefixes"][rows], z["valid_seen"], z["valid_all"], 45, 2, False, False)
+        np.testing.assert_array_equal(coords(cb.batch), np.asarray(ref["labels"], np.int32).reshape(-1, 2))
+        np.testing.assert_array_equal(cb.filt_col.numpy(), np.asarray([c for f in ref["filters"] for c in f], np.int32))
+        n += cb.batch.B
+    assert n == 91
