@@ -268,6 +268,126 @@ def metrics_from_ranks(ranks, row_ptr):
 
 
 # ------------------------------------------------------------------------------------------------
+# token-pooled embedder                   openkge/model.py:716-796 (UnigramPoolingRelationEmbedder._encode)
+#                                         torch.nn.BatchNorm1d(momentum=0.1, eps=1e-5) as built in model.py:611-616
+# ------------------------------------------------------------------------------------------------
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def token_pool(W, token_ids, ids, pool):
+    """rows of `ids` -> pooled token embeddings.  token_ids: (|vocab|, L) right-padded with 0; padded positions
+    take part like any other (the embedding's row 0 is NOT zero: init normal_ runs over the whole weight,
+    model.py:660-661; padding_idx only stops its gradient).  Returns (pooled (n,d), aux for backward)."""
+    tok = token_ids[np.asarray(ids).reshape(-1).astype(np.int64)].astype(np.int64)          # (n, L)
+    emb = W[tok]                                                                             # (n, L, d)
+    if pool == "max":
+        arg = emb.argmax(axis=1)                                                             # first maximum, like torch
+        return np.take_along_axis(emb, arg[:, None, :], axis=1)[:, 0, :], (tok, arg)
+    if pool == "mean":
+        lengths = (tok > 0).sum(axis=1, keepdims=True).astype(W.dtype) + W.dtype.type(1e-12)
+        return emb.sum(axis=1) / lengths, (tok, lengths)
+    return emb.sum(axis=1), (tok, None)
+
+
+def token_pool_backward(dW, d_pooled, aux, pool):
+    """scatter-add d(pooled) into the token table gradient; row 0 (padding_idx) receives nothing"""
+    tok, extra = aux
+    n, L = tok.shape
+    if pool == "max":
+        rows = np.take_along_axis(tok, extra, axis=1)                                        # (n, d) token per column
+        for i in range(n):
+            for k in range(d_pooled.shape[1]):
+                if rows[i, k] != 0:
+                    dW[rows[i, k], k] += d_pooled[i, k]
+        return
+    g = d_pooled / extra if pool == "mean" else d_pooled
+    for t in range(L):
+        sel = tok[:, t] != 0
+        np.add.at(dW, tok[sel, t], g[sel])
+
+
+def batchnorm_train(x, weight, bias, running_mean=None, running_var=None):
+    """training-mode BatchNorm1d over the rows of x; updates the running statistics in place (unbiased variance,
+    momentum 0.1).  Returns (y, aux)."""
+    n = x.shape[0]
+    mean = x.mean(axis=0, dtype=np.float64)
+    var = ((x - mean) ** 2).mean(axis=0, dtype=np.float64)
+    rstd = 1.0 / np.sqrt(var + BN_EPS)
+    xhat = ((x - mean) * rstd).astype(x.dtype)
+    if running_mean is not None:
+        running_mean += BN_MOMENTUM * (mean.astype(x.dtype) - running_mean)
+        running_var += BN_MOMENTUM * ((var * n / max(n - 1, 1)).astype(x.dtype) - running_var)
+    return xhat * weight + bias, (xhat, rstd.astype(x.dtype))
+
+
+def batchnorm_train_backward(dy, weight, aux):
+    xhat, rstd = aux
+    n = dy.shape[0]
+    dbias = dy.sum(axis=0, dtype=np.float64).astype(dy.dtype)
+    dweight = (dy * xhat).sum(axis=0, dtype=np.float64).astype(dy.dtype)
+    dx = weight * rstd * (dy - dbias / n - xhat * dweight / n)
+    return dx.astype(dy.dtype), dweight, dbias
+
+
+def batchnorm_eval(x, weight, bias, running_mean, running_var):
+    return (x - running_mean) / np.sqrt(running_var + x.dtype.type(BN_EPS)) * weight + bias
+
+
+def unigram_step_forward_backward(kind, We, Wr, ent_tokens, rel_tokens, po, sp, cand_ids, labels, pool="sum",
+                                  bn_ent=None, bn_rel=None, normalizer=None):
+    """AddLossModule.forward + backward for a token-pooled model (trainer.py:48-113 over model.py:762-796), bce loss,
+    dropout 0.  bn_* = dict(weight, bias, running_mean, running_var) or None.  Encoding calls happen in the
+    reference's order -- candidates, po rows, sp rows -- each with ITS OWN batch statistics.
+    Returns dict(loss, outputs, dWe, dWr, d_bn_ent (w,b), d_bn_rel (w,b))."""
+    def enc(W, tokens, ids, bn):
+        x, paux = token_pool(W, tokens, ids, pool)
+        if bn is None:
+            return x, (paux, None)
+        y, baux = batchnorm_train(x, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"])
+        return y, (paux, baux)
+
+    C, auxC = enc(We, ent_tokens, cand_ids, bn_ent)
+    parts = []
+    if po is not None:
+        r, auxr = enc(Wr, rel_tokens, po[0], bn_rel)
+        e, auxe = enc(We, ent_tokens, po[1], bn_ent)
+        parts.append((DIR_PO, e, r, auxe, auxr))
+    if sp is not None:
+        e, auxe = enc(We, ent_tokens, sp[0], bn_ent)
+        r, auxr = enc(Wr, rel_tokens, sp[1], bn_rel)
+        parts.append((DIR_SP, e, r, auxe, auxr))
+    X = np.concatenate([score_prefix(kind, d_, e, r, C) for d_, e, r, _, _ in parts])
+    B, N = X.shape
+    normalizer = float(B * N) if normalizer is None else normalizer
+    loss, g = loss_and_dscore(X, labels, LOSS_BCE, 0.0)
+    G = (g / X.dtype.type(normalizer)).astype(X.dtype)
+    dWe, dWr = np.zeros_like(We), np.zeros_like(Wr)
+    dbe = [np.zeros(We.shape[1], We.dtype), np.zeros(We.shape[1], We.dtype)]
+    dbr = [np.zeros(Wr.shape[1], Wr.dtype), np.zeros(Wr.shape[1], Wr.dtype)]
+
+    def back(d_rows, aux, W_grad, bn, acc):
+        paux, baux = aux
+        if bn is not None:
+            d_rows, dw, db = batchnorm_train_backward(d_rows, bn["weight"], baux)
+            acc[0] += dw
+            acc[1] += db
+        token_pool_backward(W_grad, d_rows, paux, pool)
+
+    dC = np.zeros_like(C)
+    row = 0
+    for d_, e, r, auxe, auxr in parts:
+        Gp = G[row:row + e.shape[0]]
+        q = prefix_query(kind, d_, e, r)
+        dC += Gp.T @ q
+        de, dr = prefix_query_backward(kind, d_, e, r, Gp @ C)
+        back(de, auxe, dWe, bn_ent, dbe)
+        back(dr, auxr, dWr, bn_rel, dbr)
+        row += e.shape[0]
+    back(dC, auxC, dWe, bn_ent, dbe)
+    return dict(loss=float(loss), outputs=X, dWe=dWe, dWr=dWr, d_bn_ent=tuple(dbe), d_bn_rel=tuple(dbr))
+
+
+# ------------------------------------------------------------------------------------------------
 # batch producer                          openkge/dataset.py:724-940 (OneToNMentionRelationDataset_collate_func)
 #                                         utils/misc.py:56-89 (packed answer groups)
 # ------------------------------------------------------------------------------------------------

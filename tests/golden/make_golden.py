@@ -23,6 +23,10 @@ Vectors:
   g6_dataset_*    OneToNMentionRelationDataset on tests/golden/toy_kg (our own synthetic 5-column TSV + id maps):
                   seen_prefixes (P,7) / packed seen_entities / all_splits_entities for train, valid, test; plus
                   shapes + sha256 of the same tensors for the reference's FB15k-237 valid/test files
+  g9_unigram_*    UnigramPoolingComplexRelationModel (token-pooled embedder, sum/mean/max pooling, batch-norm):
+                  AddLossModule forward + backward -> loss, outputs, token-table / batch-norm gradients, running
+                  stats; eval-mode precompute_embeddings_from_tokens.  The reference class lacks the attribute
+                  `entity_projection` it reads (model.py:789); the harness sets it to None on the instance.
   g5_ranks_*      OneToNMentionRelationDataset.compute_metrics (known answer + ties + mention groups)
   g8_checkpoint   the checkpoint dict Trainer.save writes (state_dict + OptimRegime.state_dict()) after two steps,
                   stored with torch.save (tensors / containers only), plus the third step's batch and result
@@ -501,6 +505,79 @@ def g6():
 
 
 # ----------------------------------------------------------------------------------------------
+# G9: token-pooled embedder
+# ----------------------------------------------------------------------------------------------
+def g9():
+    cases = [
+        # name, pool, normalize, n_ent, n_rel, d, b_po, b_sp, n_cand ("all" or int), dropout-mask capture
+        ("sum_bn_all", "sum", "batchnorm", 70, 9, 16, 6, 7, "all"),
+        ("sum_bn_shared", "sum", "batchnorm", 160, 12, 24, 10, 11, 64),
+        ("mean_bn_shared", "mean", "batchnorm", 160, 12, 24, 10, 11, 64),
+        ("max_none_shared", "max", None, 160, 12, 24, 10, 11, 64),
+        ("sum_none_all", "sum", None, 70, 9, 16, 6, 0, "all"),
+    ]
+    for ci, (name, pool, normalize, n_ent, n_rel, d, b_po, b_sp, n_cand) in enumerate(cases):
+        rng = np.random.default_rng(900 + ci)
+        L, vt_e, vt_r = 6, 40, 15
+        def token_map(n, vocab):
+            out = [[1], [1]]                                 # reserved ids 0, 1 (dataset.py:200-201)
+            for _ in range(2, n):
+                k = int(rng.integers(1, L + 3))              # some longer than max_length: the tail is kept
+                out.append([2] + rng.integers(4, vocab, size=k).tolist() + [3])
+            return tuple(out)
+        md = meta(n_ent, n_rel)
+        md.entity_id_to_tokens_map, md.relation_id_to_tokens_map = token_map(n_ent, vt_e), token_map(n_rel, vt_r)
+        md.entity_tokens_size, md.relation_tokens_size, md.max_length = vt_e, vt_r, (L, L)
+        torch.manual_seed(900 + ci)
+        m = Models.UnigramPoolingComplexRelationModel(entity_slot_size=d, relation_slot_size=d, train_data=md, pool=pool,
+                                                      normalize=normalize, dropout=0.0, sparse=False, init_std=0.3)
+        m.entity_projection = None                           # harness shim, see the module docstring
+        m.train()
+        if n_cand == "all":
+            cand = torch.arange(n_ent)[2:].int().unsqueeze(1)
+        else:
+            cand = torch.from_numpy(rng.permutation(np.arange(2, n_ent))[:n_cand].astype(np.int32)).unsqueeze(1)
+        N = cand.shape[0]
+        po = (rand_ids(rng, 2, n_rel, b_po), rand_ids(rng, 2, n_ent, b_po)) if b_po else None
+        sp = (rand_ids(rng, 2, n_ent, b_sp), rand_ids(rng, 2, n_rel, b_sp)) if b_sp else None
+        B = b_po + b_sp
+        y = dense_labels(rng, B, N)
+        kw = dict(We=npy(m.entity_embedding.weight).copy(), Wr=npy(m.relation_embedding.weight).copy(),
+                  ent_tokens=npy(m.entity_token_ids).astype(np.int32), rel_tokens=npy(m.relation_token_ids).astype(np.int32),
+                  cand=npy(cand), labels=y, pool=pool, normalize=str(normalize))
+        if normalize == "batchnorm":
+            kw.update(bn_e_w=npy(m.entity_batchnorm.weight).copy(), bn_e_b=npy(m.entity_batchnorm.bias).copy(),
+                      bn_r_w=npy(m.relation_batchnorm.weight).copy(), bn_r_b=npy(m.relation_batchnorm.bias).copy())
+        mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), bce_label_smoothing=0.0)
+        mod.train()
+        loss, hook, outputs = mod(inputs=[po, sp], labels=torch.from_numpy(y.copy()),
+                                  use_batch_shared_entities=(n_cand != "all"), batch_shared_entities=cand, epoch=1,
+                                  input_style_triple_or_prefix="right_and_left_prefix")
+        (loss.sum() / float(B * N)).backward()
+        kw.update(loss=np.float64(loss.item()), outputs=npy(outputs), normalizer=np.float64(B * N),
+                  dWe=npy(m.entity_embedding.weight.grad), dWr=npy(m.relation_embedding.weight.grad))
+        if po is not None:
+            kw.update(po_rel=npy(po[0]), po_obj=npy(po[1]))
+        if sp is not None:
+            kw.update(sp_subj=npy(sp[0]), sp_rel=npy(sp[1]))
+        if normalize == "batchnorm":
+            kw.update(d_bn_e_w=npy(m.entity_batchnorm.weight.grad), d_bn_e_b=npy(m.entity_batchnorm.bias.grad),
+                      d_bn_r_w=npy(m.relation_batchnorm.weight.grad), d_bn_r_b=npy(m.relation_batchnorm.bias.grad),
+                      run_e_mean=npy(m.entity_batchnorm.running_mean), run_e_var=npy(m.entity_batchnorm.running_var),
+                      run_r_mean=npy(m.relation_batchnorm.running_mean), run_r_var=npy(m.relation_batchnorm.running_var))
+        # evaluation: full tables from tokens with the running statistics (model.py:670-712), then prefix scores
+        m.eval()
+        with torch.no_grad():
+            m.precompute_embeddings_from_tokens()
+            kw.update(E_eval=npy(m.entity_embedding_from_tokens), R_eval=npy(m.relations_embedding_from_tokens))
+            if sp is not None:
+                kw["sp_all_eval"] = npy(m.sp_prefix_score(sp[0], sp[1]))
+            if po is not None:
+                kw["po_all_eval"] = npy(m.po_prefix_score(po[0], po[1]))
+        save(f"g9_unigram_{name}", **kw)
+
+
+# ----------------------------------------------------------------------------------------------
 # G8: checkpoint interop (Trainer.save layout, trainer.py:608-618)
 # ----------------------------------------------------------------------------------------------
 def g8():
@@ -546,7 +623,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)

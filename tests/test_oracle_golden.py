@@ -343,3 +343,40 @@ def test_g6_dataset_tensors_oracle_matches_reference():
     assert 0 < len(pref) <= len(z["train3_prefixes"]) and len(seen) <= len(z["train3_seen"])
     np.testing.assert_array_equal(pref, z["train3_prefixes"][:len(pref)])
     np.testing.assert_array_equal(seen, z["train3_seen"][:len(seen)])
+
+
+# ---------------------------------------------------------------------------------------------- G9
+def unigram_bn(z, which):
+    if str(z["normalize"]) != "batchnorm":
+        return None
+    d = z["We"].shape[1]
+    return dict(weight=z[f"bn_{which}_w"].copy(), bias=z[f"bn_{which}_b"].copy(),
+                running_mean=np.zeros(d, np.float32), running_var=np.ones(d, np.float32))
+
+
+@pytest.mark.parametrize("name", golden_names("g9_unigram_"))
+def test_g9_unigram_oracle_matches_reference(name):
+    z = golden(name)
+    po = (z["po_rel"], z["po_obj"]) if "po_rel" in z.files else None
+    sp = (z["sp_subj"], z["sp_rel"]) if "sp_subj" in z.files else None
+    bn_e, bn_r = unigram_bn(z, "e"), unigram_bn(z, "r")
+    out = ko.unigram_step_forward_backward(ko.COMPLEX, z["We"], z["Wr"], z["ent_tokens"], z["rel_tokens"], po, sp,
+                                           z["cand"], z["labels"], pool=str(z["pool"]), bn_ent=bn_e, bn_rel=bn_r)
+    np.testing.assert_allclose(out["outputs"], z["outputs"], rtol=0, atol=2e-5)
+    assert abs(out["loss"] - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    for mine, key in ((out["dWe"], "dWe"), (out["dWr"], "dWr")):
+        np.testing.assert_allclose(mine, z[key], rtol=0, atol=2e-5 * np.abs(z[key]).max())
+    if bn_e is not None:
+        for (dw, db), w in ((out["d_bn_ent"], "e"), (out["d_bn_rel"], "r")):
+            np.testing.assert_allclose(dw, z[f"d_bn_{w}_w"], rtol=0, atol=2e-5 * np.abs(z[f"d_bn_{w}_w"]).max())
+            np.testing.assert_allclose(db, z[f"d_bn_{w}_b"], rtol=0, atol=2e-5 * np.abs(z[f"d_bn_{w}_b"]).max() + 1e-9)
+        np.testing.assert_allclose(bn_e["running_mean"], z["run_e_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn_e["running_var"], z["run_e_var"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn_r["running_mean"], z["run_r_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn_r["running_var"], z["run_r_var"], rtol=1e-5, atol=1e-6)
+    # evaluation tables: every id encoded from its tokens with the running statistics
+    def table(W, tokens, bn):
+        x, _ = ko.token_pool(W, tokens, np.arange(tokens.shape[0]), str(z["pool"]))
+        return x if bn is None else ko.batchnorm_eval(x, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"])
+    np.testing.assert_allclose(table(z["We"], z["ent_tokens"], bn_e), z["E_eval"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(table(z["Wr"], z["rel_tokens"], bn_r), z["R_eval"], rtol=1e-5, atol=2e-6)
