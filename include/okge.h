@@ -198,6 +198,37 @@ size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d);
 int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const int32_t *ids, int32_t first_id,
                      int32_t n, const okge_dropout *drop, float *out, int64_t ld_out, void *stream);
 
+/* ---- token-pooled embedder ------------------------------------------------------------------------
+ * Replaces UnigramPoolingRelationEmbedder._encode (model.py:762-786) up to (not including) its final dropout,
+ * which the consumers apply while gathering rows (okge_dropout on the virtual tables):
+ *   row id -> token_ids[id][0..max_len) (right-padded with 0; TokenBasedRelationEmbedder, model.py:579-597)
+ *          -> sum | mean (/(#tokens>0 + 1e-12)) | max over the token embedding rows; padded positions take part
+ *             (row 0 of the table is an ordinary row, only its gradient is suppressed: padding_idx)
+ *          -> BatchNorm1d(eps, momentum) if bn_weight != NULL: training != 0 uses the statistics of the n rows of
+ *             THIS call and updates the running statistics (unbiased variance), else the running statistics.
+ * okge_pool_encode : raw[n][ld] = pooled rows (kept for backward), out[n][ld] = normalised rows (== raw allowed
+ *                    without batch-norm), saved[4*d] = {mean, rstd, scratch, scratch} of this call.
+ * okge_pool_backward: d_out[n][ld] -> batch-norm backward (d_bn_weight / d_bn_bias += this call's sums)
+ *                    -> scatter-add into the dense token-table gradient dW (vocab x d; row 0 untouched). */
+typedef struct okge_token_embedder {
+    const float *W;              /* token embedding table (vocab x d) */
+    const int32_t *token_ids;    /* (n_ids x max_len) */
+    int32_t vocab, d, n_ids, max_len;
+    int32_t pool;                /* 0 = sum, 1 = mean, 2 = max */
+    int32_t _pad;
+    const float *bn_weight, *bn_bias;      /* NULL: no batch-norm */
+    float *bn_running_mean, *bn_running_var;
+    float bn_eps, bn_momentum;
+} okge_token_embedder;
+
+size_t okge_pool_workspace_bytes(int32_t n, int32_t d);
+int okge_pool_encode(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n, int32_t training,
+                     float *raw, float *out, int64_t ld, float *saved, void *workspace, size_t workspace_bytes,
+                     void *stream);
+int okge_pool_backward(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n,
+                       const float *raw, const float *d_out, int64_t ld, float *saved, float *dW,
+                       float *d_bn_weight, float *d_bn_bias, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Per-triple scores of ENCODED rows, Hadamard form: RelationScorer.triple_score / forward(subj, rel, obj)
  * (model.py:43-50; ComplEx :231-238  sum s1 r1 o1 + s2 r1 o2 + s1 r2 o2 - s2 r2 o1;  DistMult :276  sum s r o).
  * Inference helper: the reference trains through the prefix path only (trainer.py:59-64). */

@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libokge_hip.so")
-SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_misc.hip", "okge_collate.cpp", "okge_dataset.cpp"]
+SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_misc.hip", "okge_pool.hip", "okge_collate.cpp", "okge_dataset.cpp"]
 HEADERS = ["okge_device.h", "okge_kernels.h", os.path.join("..", "..", "include", "okge.h")]
 
 OKGE_COMPLEX, OKGE_DISTMULT = 0, 1
@@ -29,7 +29,8 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
-           "okge_rank_counts", "okge_score_triples", "okge_collate_batch", "okge_dataset_open", "okge_dataset_sizes",
+           "okge_rank_counts", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
+           "okge_collate_batch", "okge_dataset_open", "okge_dataset_sizes",
            "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
@@ -65,6 +66,12 @@ class Shard(Structure):
 
 class Positives(Structure):
     _fields_ = [("col", c_void_p), ("row", c_void_p), ("nnz", c_int32)]
+
+
+class TokenEmbedder(Structure):
+    _fields_ = [("W", c_void_p), ("token_ids", c_void_p), ("vocab", c_int32), ("d", c_int32), ("n_ids", c_int32),
+                ("max_len", c_int32), ("pool", c_int32), ("_pad", c_int32), ("bn_weight", c_void_p), ("bn_bias", c_void_p),
+                ("bn_running_mean", c_void_p), ("bn_running_var", c_void_p), ("bn_eps", c_float), ("bn_momentum", c_float)]
 
 
 class PrefixTable(Structure):
@@ -167,6 +174,14 @@ def lib():
     L.okge_dataset_copy.argtypes = [c_void_p, c_int32, c_void_p, c_void_p, c_void_p]
     L.okge_dataset_close.restype = None
     L.okge_dataset_close.argtypes = [c_void_p]
+    L.okge_pool_workspace_bytes.restype = c_size_t
+    L.okge_pool_workspace_bytes.argtypes = [c_int32, c_int32]
+    L.okge_pool_encode.restype = c_int32
+    L.okge_pool_encode.argtypes = [POINTER(TokenEmbedder), c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]
+    L.okge_pool_backward.restype = c_int32
+    L.okge_pool_backward.argtypes = [POINTER(TokenEmbedder), c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int64,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     L.okge_scale_inplace.restype = c_int32
     L.okge_scale_inplace.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.okge_adagrad_step.restype = c_int32

@@ -566,6 +566,79 @@ int okge_score_triples(int32_t scorer, const float *subj, int64_t ld_subj, const
     return OKGE_OK;
 }
 
+// ---- token-pooled embedder -----------------------------------------------------------------------------------------
+static int check_token_embedder(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n)
+{
+    if (!e || !e->W || !e->token_ids || e->d <= 0 || e->vocab <= 0 || e->n_ids <= 0 || e->max_len <= 0)
+        return fail(OKGE_ERR_INVALID, "bad token embedder");
+    if (e->pool < 0 || e->pool > 2) return fail(OKGE_ERR_INVALID, "pool must be 0 (sum), 1 (mean) or 2 (max)");
+    if (n < 0 || (!ids && (first_id < 0 || (int64_t)first_id + n > e->n_ids)))
+        return fail(OKGE_ERR_INVALID, "row range outside the token-id table");
+    if (e->bn_weight && (!e->bn_bias || !e->bn_running_mean || !e->bn_running_var))
+        return fail(OKGE_ERR_INVALID, "batch-norm needs weight, bias and running statistics");
+    return OKGE_OK;
+}
+
+size_t okge_pool_workspace_bytes(int32_t n, int32_t d) { return n > 0 && d > 0 ? pool_workspace_bytes(n, d) : 0; }
+
+int okge_pool_encode(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n, int32_t training,
+                     float *raw, float *out, int64_t ld, float *saved, void *workspace, size_t workspace_bytes,
+                     void *stream)
+{
+    if (int rc = check_token_embedder(e, ids, first_id, n)) return rc;
+    if (!raw || !out || ld < e->d) return fail(OKGE_ERR_INVALID, "bad output rows");
+    if (n == 0) return OKGE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t err;
+    {
+        ScopedTimer tm("pool_rows", st);
+        err = launch_pool_rows(e->W, e->d, e->token_ids, e->max_len, ids, first_id, n, e->pool, raw, ld, st);
+        if (err != hipSuccess) return fail_hip(err, "pool_rows");
+    }
+    if (!e->bn_weight) {
+        if (out != raw) {
+            err = hipMemcpy2DAsync(out, ld * sizeof(float), raw, ld * sizeof(float), e->d * sizeof(float), n,
+                                   hipMemcpyDeviceToDevice, st);
+            if (err != hipSuccess) return fail_hip(err, "copy pooled rows");
+        }
+        return OKGE_OK;
+    }
+    if (out == raw) return fail(OKGE_ERR_INVALID, "with batch-norm the raw pooled rows are kept for backward: out must differ from raw");
+    ScopedTimer tm("batchnorm_forward", st);
+    if (training) {
+        if (!saved) return fail(OKGE_ERR_INVALID, "training-mode batch-norm needs the saved-statistics buffer (4*d floats)");
+        if (!workspace || workspace_bytes < pool_workspace_bytes(n, e->d)) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+        err = launch_bn_stats(raw, ld, n, e->d, e->bn_eps, e->bn_momentum, saved, e->bn_running_mean, e->bn_running_var,
+                              static_cast<float *>(workspace), st);
+        if (err != hipSuccess) return fail_hip(err, "batchnorm statistics");
+        err = launch_bn_apply(raw, ld, n, e->d, saved, saved + e->d, 0, e->bn_eps, e->bn_weight, e->bn_bias, out, ld, st);
+    } else {
+        err = launch_bn_apply(raw, ld, n, e->d, e->bn_running_mean, e->bn_running_var, 1, e->bn_eps, e->bn_weight, e->bn_bias,
+                              out, ld, st);
+    }
+    if (err != hipSuccess) return fail_hip(err, "batchnorm apply");
+    return OKGE_OK;
+}
+
+int okge_pool_backward(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n, const float *raw,
+                       const float *d_out, int64_t ld, float *saved, float *dW, float *d_bn_weight, float *d_bn_bias,
+                       void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_token_embedder(e, ids, first_id, n)) return rc;
+    if (!raw || !d_out || !dW || ld < e->d) return fail(OKGE_ERR_INVALID, "bad backward arguments");
+    if (n == 0) return OKGE_OK;
+    const bool bn = e->bn_weight != nullptr;
+    if (bn && (!saved || !d_bn_weight || !d_bn_bias)) return fail(OKGE_ERR_INVALID, "batch-norm backward needs saved statistics and gradient buffers");
+    if (bn && (!workspace || workspace_bytes < pool_workspace_bytes(n, e->d))) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("pool_backward", st);
+    hipError_t err = launch_pool_backward(e->W, e->d, e->token_ids, e->max_len, ids, first_id, n, e->pool, raw, ld, d_out, ld,
+                                          bn ? saved : nullptr, e->bn_weight, d_bn_weight, d_bn_bias, dW,
+                                          static_cast<float *>(workspace), st);
+    if (err != hipSuccess) return fail_hip(err, "pool_backward");
+    return OKGE_OK;
+}
+
 int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream)
 {
     if (!x || !alpha_dev || n < 0) return fail(OKGE_ERR_INVALID, "bad scale arguments");

@@ -80,6 +80,16 @@ hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p
 // error text for okge_last_error(), shared by the translation units of the C ABI (defined in okge_api.hip)
 int report_error(int code, const std::string &msg);
 
+size_t pool_workspace_bytes(int n, int d);
+hipError_t launch_pool_rows(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
+                            int pool, float *out, int64_t ld, hipStream_t st);
+hipError_t launch_bn_stats(const float *X, int64_t ldx, int n, int d, float eps, float momentum, float *saved,
+                           float *run_mean, float *run_var, float *partial, hipStream_t st);
+hipError_t launch_bn_apply(const float *X, int64_t ldx, int n, int d, const float *mean, const float *rstd_or_var, int is_var,
+                           float eps, const float *weight, const float *bias, float *Y, int64_t ldy, hipStream_t st);
+hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
+                                int pool, const float *X, int64_t ldx, const float *DY, int64_t lddy, float *saved,
+                                const float *weight, float *d_weight, float *d_bias, float *dW, float *partial, hipStream_t st);
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,

@@ -1,0 +1,353 @@
+"""Token-pooled embedder: UnigramPoolingRelationEmbedder + TokenBasedRelationEmbedder
+(openkge/model.py:561-796) over the HIP kernels of csrc/okge_pool.hip, and the training step that drives the fused
+prefix-scoring path on rows computed from tokens.
+
+Design: the pooled (and batch-normed) rows of one batch -- candidates, po objects, sp subjects; po / sp relations -- are
+written into two small "virtual" tables; the unchanged fused step (score -> loss -> backward, dropout included) runs on
+those tables; its dense row gradients then go back through batch-norm and the pooling into the token tables' dense
+gradients, and Adagrad sweeps the token tables and the batch-norm parameters.  Every `_encode` call of the reference
+(candidates, po rows, sp rows -- trainer.py:75-91) normalises with ITS OWN batch statistics and updates the running
+statistics; that order is kept.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as N
+from . import hotpath as H
+from .model import ComplexRelationScorer, DistmultRelationScorer, RelationEmbedder
+
+POOLS = {"sum": 0, "mean": 1, "max": 2}
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1                     # torch.nn.BatchNorm1d(momentum=0.1, eps=1e-5), model.py:611-612
+
+
+def token_id_matrix(id_to_tokens_map, max_len, device="cpu"):
+    """TokenBasedRelationEmbedder.__init__ (model.py:579-597): row i = the LAST max_len tokens of item i,
+    right-padded with 0."""
+    out = torch.zeros((len(id_to_tokens_map), max_len), dtype=torch.int32)
+    for i, seq in enumerate(id_to_tokens_map):
+        tail = list(seq)[-max_len:]
+        out[i, :len(tail)] = torch.tensor(tail, dtype=torch.int32)
+    return out.to(device)
+
+
+class TokenSlot:
+    """One embedder slot (entity or relation): token table, token-id matrix, optional batch-norm, gradients."""
+
+    def __init__(self, W, token_ids, pool="sum", batchnorm=False, bn_weight=None, bn_bias=None):
+        self.W, self.token_ids, self.pool = W, token_ids.to(torch.int32).contiguous(), pool
+        d, dev = W.shape[1], W.device
+        self.d = d
+        # batch-norm parameters live in one flat buffer [weight | bias] so that one Adagrad launch covers them
+        self.bn = None
+        if batchnorm:
+            self.bn = torch.empty(2 * d, dtype=torch.float32, device=dev)
+            self.bn[:d] = torch.rand(d) if bn_weight is None else bn_weight        # init.uniform_(weight), model.py:613
+            self.bn[d:] = 0.0 if bn_bias is None else bn_bias
+            self.running_mean = torch.zeros(d, dtype=torch.float32, device=dev)
+            self.running_var = torch.ones(d, dtype=torch.float32, device=dev)
+            self.d_bn = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+            self.sum_bn = torch.zeros(2 * d, dtype=torch.float32, device=dev)
+        self.dW = torch.zeros_like(W)
+        self.sumW = torch.zeros_like(W)
+
+    @property
+    def bn_weight(self):
+        return None if self.bn is None else self.bn[:self.d]
+
+    @property
+    def bn_bias(self):
+        return None if self.bn is None else self.bn[self.d:]
+
+    def c(self):
+        e = N.TokenEmbedder()
+        e.W, e.token_ids = self.W.data_ptr(), self.token_ids.data_ptr()
+        e.vocab, e.d, e.n_ids, e.max_len = self.W.shape[0], self.d, self.token_ids.shape[0], self.token_ids.shape[1]
+        e.pool = POOLS[self.pool]
+        if self.bn is not None:
+            e.bn_weight, e.bn_bias = self.bn_weight.data_ptr(), self.bn_bias.data_ptr()
+            e.bn_running_mean, e.bn_running_var = self.running_mean.data_ptr(), self.running_var.data_ptr()
+            e.bn_eps, e.bn_momentum = BN_EPS, BN_MOMENTUM
+        return e
+
+
+class PoolEngine:
+    """ctypes driver of okge_pool_encode / okge_pool_backward."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.lib = N.lib()
+        self._ws, self._ws_bytes = None, 0
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, n, d):
+        need = int(self.lib.okge_pool_workspace_bytes(n, d))
+        if need > self._ws_bytes:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        return self._ws
+
+    def encode(self, slot: TokenSlot, ids, first_id, n, training, raw, out, saved):
+        """raw / out: (n, d) row blocks (views into the virtual tables); saved: (4*d,) or None without batch-norm"""
+        if n == 0:
+            return
+        ws = self._workspace(n, slot.d)
+        e = slot.c()
+        N.check(self.lib.okge_pool_encode(ctypes.byref(e), None if ids is None else ids.data_ptr(), int(first_id), int(n),
+                                          int(training), raw.data_ptr(), out.data_ptr(), raw.stride(0),
+                                          None if saved is None else saved.data_ptr(), ws.data_ptr(), self._ws_bytes,
+                                          self._stream()), "okge_pool_encode")
+
+    def backward(self, slot: TokenSlot, ids, first_id, n, raw, d_out, saved):
+        if n == 0:
+            return
+        ws = self._workspace(n, slot.d)
+        e = slot.c()
+        bn = slot.bn is not None
+        N.check(self.lib.okge_pool_backward(ctypes.byref(e), None if ids is None else ids.data_ptr(), int(first_id), int(n),
+                                            raw.data_ptr(), d_out.data_ptr(), raw.stride(0),
+                                            saved.data_ptr() if bn else None, slot.dW.data_ptr(),
+                                            slot.d_bn[:slot.d].data_ptr() if bn else None,
+                                            slot.d_bn[slot.d:].data_ptr() if bn else None, ws.data_ptr(), self._ws_bytes,
+                                            self._stream()), "okge_pool_backward")
+
+
+def _i32(t, dev):
+    return None if t is None else t.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
+
+
+class TokenPooledTrainStep:
+    """forward + loss + backward + Adagrad for UnigramPooling{Complex,Distmult}RelationModel
+    (Trainer.compute_one_batch, trainer.py:181-257, over model.py:762-796)."""
+
+    def __init__(self, entity: TokenSlot, relation: TokenSlot, scorer, loss="bce", lr=0.1, weight_decay=1e-10, eps=1e-8,
+                 label_smoothing=0.0, dropout=0.0, seed=0, engine=None):
+        self.entity, self.relation, self.scorer, self.loss = entity, relation, scorer, loss
+        self.lr, self.weight_decay, self.eps, self.label_smoothing = lr, weight_decay, eps, label_smoothing
+        self.dropout, self.seed, self.steps = dropout, seed, 0
+        self.device = entity.W.device
+        self.engine = engine or H.HotPath(self.device)
+        self.pool = PoolEngine(self.device)
+        self.loss_out = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._rows = 0
+
+    def _buffers(self, n_ent_rows, n_rel_rows):
+        d = self.entity.d
+        if n_ent_rows > self._rows or n_rel_rows > getattr(self, "_rrows", 0):
+            dev = self.device
+            self._rows, self._rrows = n_ent_rows, n_rel_rows
+            self.EV, self.EX, self.dEV = (torch.zeros((n_ent_rows, d), device=dev) for _ in range(3))
+            self.RV, self.RX, self.dRV = (torch.zeros((n_rel_rows, d), device=dev) for _ in range(3))
+            self.saved = torch.zeros((5, 4 * d), device=dev)
+        return self.EV, self.EX, self.dEV, self.RV, self.RX, self.dRV
+
+    def step(self, batch: H.PrefixBatch, normalizer=None):
+        """`batch` carries ENTITY / RELATION ids exactly as for the lookup models."""
+        loss = self.forward_backward(batch, normalizer)
+        self.optimizer_step()
+        return loss
+
+    def forward_backward(self, batch: H.PrefixBatch, normalizer=None, scores=None):
+        """Leaves the dense gradients in entity/relation .dW and .d_bn ([d weight | d bias])."""
+        self.steps += 1
+        dev = self.device
+        n_po, n_sp, N_c = batch.n_po, batch.n_sp, batch.n_candidates
+        B = n_po + n_sp
+        EV, EX, dEV, RV, RX, dRV = self._buffers(N_c + B, B)
+        ent, rel, pe = self.entity, self.relation, self.pool
+        sv = self.saved
+        bn_e, bn_r = ent.bn is not None, rel.bn is not None
+        # the reference's encode order: candidates, (po rel, po obj), (sp subj, sp rel)   -- trainer.py:75-91
+        calls = [(ent, _i32(batch.cand_ids, dev), batch.cand_first, N_c, EX[:N_c], EV[:N_c], dEV[:N_c], sv[0] if bn_e else None),
+                 (rel, _i32(batch.po_rel, dev), 0, n_po, RX[:n_po], RV[:n_po], dRV[:n_po], sv[1] if bn_r else None),
+                 (ent, _i32(batch.po_obj, dev), 0, n_po, EX[N_c:N_c + n_po], EV[N_c:N_c + n_po], dEV[N_c:N_c + n_po], sv[2] if bn_e else None),
+                 (ent, _i32(batch.sp_subj, dev), 0, n_sp, EX[N_c + n_po:N_c + B], EV[N_c + n_po:N_c + B], dEV[N_c + n_po:N_c + B], sv[3] if bn_e else None),
+                 (rel, _i32(batch.sp_rel, dev), 0, n_sp, RX[n_po:B], RV[n_po:B], dRV[n_po:B], sv[4] if bn_r else None)]
+        for slot, ids, first, n, raw, out, _, saved in calls:
+            pe.encode(slot, ids, first, n, True, raw, out if slot.bn is not None else raw, saved)
+        EVt, RVt = (EV if bn_e else EX), (RV if bn_r else RX)
+        # the fused step on the virtual tables: candidates are rows 0..N-1, prefix entities follow
+        ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
+        p, s, t = self.dropout, self.seed, self.steps
+        vb = H.PrefixBatch(po_rel=ar(0, n_po) if n_po else None, po_obj=ar(N_c, N_c + n_po) if n_po else None,
+                           sp_subj=ar(N_c + n_po, N_c + B) if n_sp else None, sp_rel=ar(n_po, B) if n_sp else None,
+                           pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=N_c,
+                           drop_cand=H.DropoutSpec(p, s, H.STREAM_CAND, t), drop_po_ent=H.DropoutSpec(p, s, H.STREAM_PO_ENT, t),
+                           drop_sp_ent=H.DropoutSpec(p, s, H.STREAM_SP_ENT, t), drop_po_rel=H.DropoutSpec(p, s, H.STREAM_PO_REL, t),
+                           drop_sp_rel=H.DropoutSpec(p, s, H.STREAM_SP_REL, t))
+        self.engine.forward_backward(EVt[:N_c + B], RVt[:B], self.scorer, vb, dEV[:N_c + B], dRV[:B], loss=self.loss,
+                                     label_smoothing=self.label_smoothing, normalizer=normalizer, loss_out=self.loss_out,
+                                     scores=scores, grads_zero=True)
+        for slot, ids, first, n, raw, _, d_out, saved in calls:
+            pe.backward(slot, ids, first, n, raw, d_out, saved)
+        dEV[:N_c + B].zero_()
+        dRV[:B].zero_()
+        return self.loss_out
+
+    def optimizer_step(self):
+        eng, e, r = self.engine, self.entity, self.relation
+        eng.adagrad2(e.W, e.dW, e.sumW, r.W, r.dW, r.sumW, self.lr, self.weight_decay, self.eps, zero_grad=True)
+        if e.bn is not None and r.bn is not None:
+            eng.adagrad2(e.bn, e.d_bn, e.sum_bn, r.bn, r.d_bn, r.sum_bn, self.lr, self.weight_decay, self.eps, zero_grad=True)
+        else:
+            for sl in (e, r):
+                if sl.bn is not None:
+                    eng.adagrad(sl.bn, sl.d_bn, sl.sum_bn, self.lr, self.weight_decay, self.eps, zero_grad=True)
+        for sl, bn in getattr(self, "module_batchnorms", ()):          # keep an attached nn.Module's parameters current
+            bn.weight.data.copy_(sl.bn_weight)
+            bn.bias.data.copy_(sl.bn_bias)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# API-compatible model classes (inference protocol; training goes through TokenPooledTrainStep)
+# ------------------------------------------------------------------------------------------------------------------
+class UnigramPoolingRelationEmbedder(RelationEmbedder):
+    """openkge/model.py:561-796.  Implemented: pool sum|mean|max, normalize None|'batchnorm', dropout; not implemented
+    (raise): normalize='norm', activation, project_relation, sparse gradients."""
+
+    def __init__(self, entity_slot_size, relation_slot_size, train_data, pool='sum', normalize=None, dropout=0.0,
+                 entity_dropout=None, relation_dropout=None, sparse=False, init_std=0.01, activation=None,
+                 project_relation=False, seed=0):
+        super().__init__()
+        if normalize not in (None, 'batchnorm') or activation is not None or project_relation or sparse:
+            raise NotImplementedError("token-pooled path implements pool sum/mean/max with optional batchnorm only")
+        if relation_slot_size is None or relation_slot_size <= 0:
+            relation_slot_size = entity_slot_size
+        if relation_slot_size != entity_slot_size:
+            raise NotImplementedError("relation slot size must equal the entity slot size without a relation projection")
+        self.train_data, self.slot_size, self.pool, self.normalize = train_data, entity_slot_size, pool, normalize
+        self.entity_dropout = entity_dropout if entity_dropout else dropout            # model.py:757-758
+        self.relation_dropout = relation_dropout if relation_dropout else dropout
+        self.register_buffer('entity_token_ids', token_id_matrix(train_data.entity_id_to_tokens_map, train_data.max_length[0]))
+        self.register_buffer('relation_token_ids', token_id_matrix(train_data.relation_id_to_tokens_map, train_data.max_length[1]))
+        self.entity_embedding = torch.nn.Embedding(train_data.entity_tokens_size, entity_slot_size, padding_idx=0)
+        self.relation_embedding = torch.nn.Embedding(train_data.relation_tokens_size, entity_slot_size, padding_idx=0)
+        torch.nn.init.normal_(self.entity_embedding.weight.data, std=init_std)         # model.py:660-661 (row 0 included)
+        torch.nn.init.normal_(self.relation_embedding.weight.data, std=init_std)
+        self.entity_batchnorm = self.relation_batchnorm = None
+        if normalize == 'batchnorm':
+            self.entity_batchnorm = torch.nn.BatchNorm1d(entity_slot_size, momentum=BN_MOMENTUM, eps=BN_EPS)
+            self.relation_batchnorm = torch.nn.BatchNorm1d(entity_slot_size, momentum=BN_MOMENTUM, eps=BN_EPS)
+            torch.nn.init.uniform_(self.entity_batchnorm.weight)
+            torch.nn.init.uniform_(self.relation_batchnorm.weight)
+        self.entity_projection = self.relation_projection = None                      # the attribute model.py:789 reads
+        self.entity_embedding_from_tokens = self.relations_embedding_from_tokens = None
+        self.dropout_seed, self.dropout_step = seed, 0
+        self._pool_engine = self._engine = None
+
+    # -- plumbing ----------------------------------------------------------------------------------------------
+    def engine(self):
+        dev = self.entity_embedding.weight.device
+        if self._engine is None or self._engine.device != dev:
+            self._engine, self._pool_engine = H.HotPath(dev), PoolEngine(dev)
+        return self._engine
+
+    def _slot(self, relation):
+        emb, tok, bn = (self.relation_embedding, self.relation_token_ids, self.relation_batchnorm) if relation else \
+            (self.entity_embedding, self.entity_token_ids, self.entity_batchnorm)
+        s = TokenSlot.__new__(TokenSlot)
+        s.W, s.token_ids, s.pool, s.d, s.bn = emb.weight.data, tok, self.pool, self.slot_size, None
+        if bn is not None:
+            s.bn = torch.cat([bn.weight.data, bn.bias.data])
+            s.running_mean, s.running_var = bn.running_mean, bn.running_var
+        return s
+
+    def _encode(self, ids, relation, stream):
+        """pool -> batch-norm (batch statistics in training mode, running statistics otherwise) -> dropout -> (n,1,d)"""
+        eng = self.engine()
+        ids = ids.reshape(-1).to(torch.int32).contiguous()
+        n, d = ids.numel(), self.slot_size
+        slot = self._slot(relation)
+        raw = torch.empty((n, d), device=ids.device)
+        out = torch.empty_like(raw) if slot.bn is not None else raw
+        saved = torch.empty(4 * d, device=ids.device) if slot.bn is not None else None
+        self._pool_engine.encode(slot, ids, 0, n, self.training, raw, out, saved)
+        p = (self.relation_dropout if relation else self.entity_dropout) if self.training else 0.0
+        if p > 0:
+            out = eng.encode_rows(out, None, 0, n, H.DropoutSpec(p, self.dropout_seed, stream, self.dropout_step))
+        return out.unsqueeze(1)
+
+    def encode_subj(self, subj):
+        return self._encode(subj, False, H.STREAM_SP_ENT)
+
+    def encode_obj(self, obj):
+        return self._encode(obj, False, H.STREAM_PO_ENT)
+
+    def encode_rel(self, rel):
+        return self._encode(rel, True, H.STREAM_SP_REL)
+
+    # -- TokenBasedRelationEmbedder: tables precomputed from tokens (model.py:624-712) -----------------------------
+    def train(self, mode=True):
+        self.entity_embedding_from_tokens = self.relations_embedding_from_tokens = None
+        return super().train(mode)
+
+    def precompute_embeddings_from_tokens(self):
+        if self.entity_embedding_from_tokens is None:
+            was_training = self.training
+            super().train(False)                       # the reference calls self.eval() here and stays in eval mode
+            dev = self.entity_embedding.weight.device
+            ar = lambda n: torch.arange(n, dtype=torch.int32, device=dev)      # noqa: E731
+            self.entity_embedding_from_tokens = self._encode(ar(self.train_data.entities_size), False, H.STREAM_CAND).squeeze(1)
+            self.relations_embedding_from_tokens = self._encode(ar(self.train_data.relations_size), True, H.STREAM_SP_REL).squeeze(1)
+            del was_training
+
+    def get_all_subj(self):
+        self.precompute_embeddings_from_tokens()
+        return self.entity_embedding_from_tokens[self.train_data.min_entities_size:]
+
+    get_all_obj = get_all_subj
+
+    def get_all_rel(self):
+        self.precompute_embeddings_from_tokens()
+        return self.relations_embedding_from_tokens[self.train_data.min_entities_size:]        # sic, model.py:630
+
+    def get_subj(self, subj):
+        self.precompute_embeddings_from_tokens()
+        return self.entity_embedding_from_tokens[subj].unsqueeze(0)
+
+    get_obj = get_subj
+
+    def get_rel(self, rel):
+        self.precompute_embeddings_from_tokens()
+        return self.relations_embedding_from_tokens[rel]
+
+    def get_slot_size(self):
+        return self.slot_size
+
+    # -- prefix scoring: RelationScorer.sp_prefix_score / po_prefix_score (model.py:52-74) ------------------------------
+    def _prefix_score(self, batch: H.PrefixBatch, many=None):
+        if many is None:
+            many = self.get_all_obj()
+        if batch.sp_subj is not None:
+            return self._score(self.encode_subj(batch.sp_subj), self.encode_rel(batch.sp_rel), many, prefix=True, sp=True, po=False)
+        return self._score(many, self.encode_rel(batch.po_rel), self.encode_obj(batch.po_obj), prefix=True, sp=False, po=True)
+
+    def train_step(self, loss="bce", lr=0.1, weight_decay=1e-10, eps=1e-8, label_smoothing=0.0):
+        """The training driver for this model: shares the module's parameters (updated in place)."""
+        slots = []
+        for emb, tok, bn in ((self.entity_embedding, self.entity_token_ids, self.entity_batchnorm),
+                             (self.relation_embedding, self.relation_token_ids, self.relation_batchnorm)):
+            s = TokenSlot(emb.weight.data, tok, self.pool, bn is not None, None if bn is None else bn.weight.data,
+                          None if bn is None else bn.bias.data)
+            if bn is not None:
+                s.running_mean, s.running_var = bn.running_mean, bn.running_var
+            slots.append(s)
+        st = TokenPooledTrainStep(slots[0], slots[1], self.scorer_name, loss=loss, lr=lr, weight_decay=weight_decay, eps=eps,
+                                  label_smoothing=label_smoothing, dropout=self.entity_dropout, seed=self.dropout_seed)
+        if self.entity_batchnorm is not None:
+            st.module_batchnorms = ((slots[0], self.entity_batchnorm), (slots[1], self.relation_batchnorm))
+        return st
+
+
+class UnigramPoolingComplexRelationModel(ComplexRelationScorer, UnigramPoolingRelationEmbedder):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+
+class UnigramPoolingDistmultRelationModel(DistmultRelationScorer, UnigramPoolingRelationEmbedder):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)

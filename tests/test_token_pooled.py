@@ -1,0 +1,124 @@
+"""Token-pooled embedder on the GPU against vectors produced by the reference's
+UnigramPoolingComplexRelationModel + AddLossModule (tests/golden/g9_unigram_*.npz) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_names
+from oracle import kge_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t if dtype is None else t.to(dtype)).cuda()
+
+
+def slots(z):
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenSlot
+    bn = str(z["normalize"]) == "batchnorm"
+    e = TokenSlot(dev(z["We"]), dev(z["ent_tokens"]), str(z["pool"]), bn, dev(z["bn_e_w"]) if bn else None, dev(z["bn_e_b"]) if bn else None)
+    r = TokenSlot(dev(z["Wr"]), dev(z["rel_tokens"]), str(z["pool"]), bn, dev(z["bn_r_w"]) if bn else None, dev(z["bn_r_b"]) if bn else None)
+    return e, r, bn
+
+
+def batch_of(z):
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch, positives_from_dense
+    b = PrefixBatch()
+    if "po_rel" in z.files:
+        b.po_rel, b.po_obj = dev(z["po_rel"].reshape(-1)), dev(z["po_obj"].reshape(-1))
+    if "sp_subj" in z.files:
+        b.sp_subj, b.sp_rel = dev(z["sp_subj"].reshape(-1)), dev(z["sp_rel"].reshape(-1))
+    b.cand_ids = dev(z["cand"].reshape(-1).astype(np.int32))
+    b.pos_row, b.pos_col = positives_from_dense(dev(z["labels"]))
+    return b
+
+
+@pytest.mark.parametrize("name", golden_names("g9_unigram_"))
+def test_train_forward_backward_matches_reference(okge_lib, name):
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep
+    z = golden(name)
+    e, r, bn = slots(z)
+    st = TokenPooledTrainStep(e, r, "complex", lr=0.1)
+    B, N = z["labels"].shape
+    scores = torch.empty((B, (N + 3) // 4 * 4), device="cuda:0")[:, :N]
+    loss = st.forward_backward(batch_of(z), scores=scores)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(scores.cpu().numpy(), z["outputs"], rtol=0, atol=1e-4)
+    assert abs(float(loss[0]) - float(z["loss"])) <= 3e-5 * abs(float(z["loss"]))
+    for mine, key in ((e.dW, "dWe"), (r.dW, "dWr")):
+        np.testing.assert_allclose(mine.cpu().numpy(), z[key], rtol=0, atol=5e-5 * np.abs(z[key]).max())
+    assert float(e.dW[0].abs().sum()) == 0 and float(r.dW[0].abs().sum()) == 0          # padding_idx row: no gradient
+    if bn:
+        d = e.d
+        for sl, w in ((e, "e"), (r, "r")):
+            np.testing.assert_allclose(sl.d_bn[:d].cpu().numpy(), z[f"d_bn_{w}_w"], rtol=0, atol=5e-5 * np.abs(z[f"d_bn_{w}_w"]).max())
+            np.testing.assert_allclose(sl.d_bn[d:].cpu().numpy(), z[f"d_bn_{w}_b"], rtol=0, atol=5e-5 * np.abs(z[f"d_bn_{w}_b"]).max() + 1e-8)
+            np.testing.assert_allclose(sl.running_mean.cpu().numpy(), z[f"run_{w}_mean"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(sl.running_var.cpu().numpy(), z[f"run_{w}_var"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", golden_names("g9_unigram_"))
+def test_model_api_eval_tables_and_scores(okge_lib, name):
+    """precompute_embeddings_from_tokens + sp/po_prefix_score in eval mode, after the training step's running-stat
+    update (the fixture's eval outputs were taken after one training forward)."""
+    from open_knowledge_graph_embeddings_amd.dataset import EntityRelationDatasetMeta
+    from open_knowledge_graph_embeddings_amd.token_pooled import UnigramPoolingComplexRelationModel
+    z = golden(name)
+    n_ent, L = z["ent_tokens"].shape
+    n_rel = z["rel_tokens"].shape[0]
+    md = EntityRelationDatasetMeta(entities_size=n_ent, relations_size=n_rel, entity_tokens_size=z["We"].shape[0],
+                                   relation_tokens_size=z["Wr"].shape[0], max_length=(L, L),
+                                   entity_id_to_tokens_map=[[int(t) for t in row if t] or [0] for row in z["ent_tokens"]],
+                                   relation_id_to_tokens_map=[[int(t) for t in row if t] or [0] for row in z["rel_tokens"]])
+    bn = str(z["normalize"]) == "batchnorm"
+    m = UnigramPoolingComplexRelationModel(entity_slot_size=z["We"].shape[1], relation_slot_size=z["We"].shape[1], train_data=md,
+                                           pool=str(z["pool"]), normalize="batchnorm" if bn else None, dropout=0.0, init_std=0.3)
+    np.testing.assert_array_equal(m.entity_token_ids.numpy(), z["ent_tokens"])
+    m = m.cuda()
+    m.entity_embedding.weight.data.copy_(dev(z["We"]))
+    m.relation_embedding.weight.data.copy_(dev(z["Wr"]))
+    if bn:
+        for mod, w in ((m.entity_batchnorm, "e"), (m.relation_batchnorm, "r")):
+            mod.weight.data.copy_(dev(z[f"bn_{w}_w"]))
+            mod.bias.data.copy_(dev(z[f"bn_{w}_b"]))
+            mod.running_mean.copy_(dev(z[f"run_{w}_mean"]))
+            mod.running_var.copy_(dev(z[f"run_{w}_var"]))
+    m.eval()
+    m.precompute_embeddings_from_tokens()
+    np.testing.assert_allclose(m.entity_embedding_from_tokens.cpu().numpy(), z["E_eval"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(m.relations_embedding_from_tokens.cpu().numpy(), z["R_eval"], rtol=1e-5, atol=2e-6)
+    if "sp_all_eval" in z.files:
+        out = m.sp_prefix_score(dev(z["sp_subj"]), dev(z["sp_rel"]))
+        np.testing.assert_allclose(out.cpu().numpy(), z["sp_all_eval"], rtol=0, atol=1e-4)
+    if "po_all_eval" in z.files:
+        out = m.po_prefix_score(dev(z["po_rel"]), dev(z["po_obj"]))
+        np.testing.assert_allclose(out.cpu().numpy(), z["po_all_eval"], rtol=0, atol=1e-4)
+
+
+def test_token_pooled_training_trajectory_vs_oracle(okge_lib):
+    """three optimisation steps (sum pooling + batch-norm, dropout 0): loss curve and tables against the oracle"""
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep
+    z = golden("g9_unigram_sum_bn_shared")
+    e, r, _ = slots(z)
+    st = TokenPooledTrainStep(e, r, "complex", lr=0.1)
+    We, Wr = z["We"].copy(), z["Wr"].copy()
+    d = We.shape[1]
+    bn_e = dict(weight=z["bn_e_w"].copy(), bias=z["bn_e_b"].copy(), running_mean=np.zeros(d, np.float32), running_var=np.ones(d, np.float32))
+    bn_r = dict(weight=z["bn_r_w"].copy(), bias=z["bn_r_b"].copy(), running_mean=np.zeros(d, np.float32), running_var=np.ones(d, np.float32))
+    sums = [np.zeros_like(a) for a in (We, Wr, bn_e["weight"], bn_e["bias"], bn_r["weight"], bn_r["bias"])]
+    for _ in range(3):
+        loss = float(st.step(batch_of(z))[0])
+        out = ko.unigram_step_forward_backward(ko.COMPLEX, We, Wr, z["ent_tokens"], z["rel_tokens"], (z["po_rel"], z["po_obj"]),
+                                               (z["sp_subj"], z["sp_rel"]), z["cand"], z["labels"], pool="sum", bn_ent=bn_e, bn_rel=bn_r)
+        assert abs(loss - out["loss"]) <= 5e-5 * abs(out["loss"])
+        params = (We, Wr, bn_e["weight"], bn_e["bias"], bn_r["weight"], bn_r["bias"])
+        grads = (out["dWe"], out["dWr"], out["d_bn_ent"][0], out["d_bn_ent"][1], out["d_bn_rel"][0], out["d_bn_rel"][1])
+        for p_, g_, s_ in zip(params, grads, sums):
+            ko.adagrad_step(p_, g_, s_, 0.1)
+    # Adagrad's early steps amplify 1e-12-level gradient differences where |g| is tiny (see adagrad_tol in
+    # tests/test_oracle_golden.py); the per-step losses above are the tight check, the tables a coarse one
+    close = np.isclose(e.W.cpu().numpy(), We, rtol=2e-3, atol=2e-4)
+    assert close.mean() > 0.95 and np.abs(e.W.cpu().numpy() - We).max() < 0.05
+    np.testing.assert_allclose(e.running_mean.cpu().numpy(), bn_e["running_mean"], rtol=1e-3, atol=1e-4)
