@@ -53,6 +53,9 @@ typedef struct okge_dropout {
     uint32_t       _pad;
     uint64_t       seed;
     const uint8_t *keep;
+    /* Optional DEVICE counter: if non-NULL the kernels read `step` from it when they run (and ignore the
+     * host value above), so a captured HIP graph draws a fresh mask on every replay. */
+    const uint32_t *step_dev;
 } okge_dropout;
 
 /* One batch of prefixes.  Replaces the `inputs` list AddLossModule.forward receives
@@ -70,7 +73,8 @@ typedef struct okge_prefix_batch {
 /* Candidate entity set shared by every row of the batch (trainer.py:75-87).
  * ids == NULL means the contiguous range first_id .. first_id + n - 1 (1-vs-all: first_id = 2,
  * model.py:512-523 `weight[min_entities_size:]`); otherwise ids[n] (batch-shared sample,
- * model.py:76-77), which must not contain duplicates for the training entry point. */
+ * model.py:76-77); an id may repeat (its gradient rows are then accumulated with atomics, see
+ * OKGE_TRAIN_UNIQUE_CANDIDATES). */
 typedef struct okge_candidates {
     const int32_t *ids;
     int32_t        first_id;

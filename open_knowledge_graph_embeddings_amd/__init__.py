@@ -7,4 +7,6 @@ HIP kernels for gfx950 behind the C ABI declared in ``include/okge.h``.
 from . import _native  # noqa: F401
 from ._native import OkgeError, build_native  # noqa: F401
 
+from . import model, token_pooled  # noqa: F401,E402  (token_pooled registers its classes in model.Models)
+
 __all__ = ["OkgeError", "build_native"]

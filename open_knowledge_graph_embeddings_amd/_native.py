@@ -41,7 +41,7 @@ class OkgeError(RuntimeError):
 
 class Dropout(Structure):
     _fields_ = [("p", c_float), ("stream", c_uint32), ("step", c_uint32), ("_pad", c_uint32), ("seed", c_uint64),
-                ("keep", c_void_p)]
+                ("keep", c_void_p), ("step_dev", c_void_p)]
 
 
 class PrefixBatch(Structure):

@@ -93,6 +93,7 @@ DropDev to_dev(const okge_dropout &d)
         r.k1 = (uint32_t)(d.seed >> 32);
         r.stream = d.stream;
         r.step = d.step;
+        r.step_dev = d.step_dev;
     }
     return r;
 }
@@ -572,6 +573,7 @@ static int check_token_embedder(const okge_token_embedder *e, const int32_t *ids
     if (!e || !e->W || !e->token_ids || e->d <= 0 || e->vocab <= 0 || e->n_ids <= 0 || e->max_len <= 0)
         return fail(OKGE_ERR_INVALID, "bad token embedder");
     if (e->pool < 0 || e->pool > 2) return fail(OKGE_ERR_INVALID, "pool must be 0 (sum), 1 (mean) or 2 (max)");
+    if (e->max_len > 64) return fail(OKGE_ERR_UNSUPPORTED, "token sequences longer than 64 are not supported");
     if (n < 0 || (!ids && (first_id < 0 || (int64_t)first_id + n > e->n_ids)))
         return fail(OKGE_ERR_INVALID, "row range outside the token-id table");
     if (e->bn_weight && (!e->bn_bias || !e->bn_running_mean || !e->bn_running_var))

@@ -18,7 +18,10 @@ struct DropDev {
     uint32_t       k0, k1; // philox key = seed
     uint32_t       stream, step;
     int32_t        enabled;
+    const uint32_t *step_dev;   // device-resident step counter (graph replay) or nullptr
 };
+
+__device__ __forceinline__ uint32_t drop_step(const DropDev &dr) { return dr.step_dev ? *dr.step_dev : dr.step; }
 
 // ---- Philox4x32-10 (Salmon et al. 2011), Random123 known-answer vectors in tests/ -------------------
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -49,7 +52,7 @@ __device__ __forceinline__ uint32_t drop_keep8(const DropDev &dr, uint32_t row_p
             if (8 * o8 + e < d && kp[e]) bits |= 1u << e;
         return bits;
     }
-    const uint4 u = philox4x32_10(row_pos, (uint32_t)o8, dr.stream, dr.step, dr.k0, dr.k1);
+    const uint4 u = philox4x32_10(row_pos, (uint32_t)o8, dr.stream, drop_step(dr), dr.k0, dr.k1);
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -63,7 +66,7 @@ __device__ __forceinline__ float drop_mult1(const DropDev &dr, uint32_t row_pos,
 {
     if (!dr.enabled) return 1.f;
     if (dr.keep) return dr.keep[(size_t)row_pos * d + k] ? dr.scale : 0.f;
-    const uint4 u = philox4x32_10(row_pos, (uint32_t)(k >> 3), dr.stream, dr.step, dr.k0, dr.k1);
+    const uint4 u = philox4x32_10(row_pos, (uint32_t)(k >> 3), dr.stream, drop_step(dr), dr.k0, dr.k1);
     const int e = k & 7;
     const uint32_t w = (e >> 1) == 0 ? u.x : (e >> 1) == 1 ? u.y : (e >> 1) == 2 ? u.z : u.w;
     return ((w >> (16 * (e & 1))) & 0xFFFFu) >= dr.thr ? dr.scale : 0.f;

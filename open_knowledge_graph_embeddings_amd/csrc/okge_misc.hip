@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void kl_count_pos_kernel(const int32_t *__rest
                                                            float *__restrict__ row_ysum)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nnz) atomicAdd(row_ysum + pos_row[i], 1.0f);
+    if (i < nnz && pos_row[i] >= 0) atomicAdd(row_ysum + pos_row[i], 1.0f);      // row < 0: padding (fixed-size graphs)
 }
 
 __global__ __launch_bounds__(256) void kl_row_lse_kernel(const float *__restrict__ stats, int tiles, int B, int Bpad,

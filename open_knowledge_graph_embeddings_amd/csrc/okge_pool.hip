@@ -17,7 +17,7 @@ namespace okge {
 namespace {
 
 constexpr int POOL_SUM = 0, POOL_MEAN = 1, POOL_MAX = 2;
-constexpr int STAT_ROWS = 64;          // rows per partial-sum workgroup
+constexpr int STAT_ROWS = 32;          // rows per partial-sum workgroup
 
 __device__ __forceinline__ int row_id(const int32_t *ids, int first_id, int i) { return ids ? ids[i] : first_id + i; }
 
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(128) void pool_rows_kernel(const float *__restrict_
     }
 }
 
-// MODE 0: partial[b][0][k] = sum_i x            MODE 1: sum_i (x - mean)^2
+// MODE 0: partial[b][0][k] = mean of the block's rows, partial[b][1][k] = their sum of squared deviations from it
+//         (two sweeps over 64 rows that stay in cache; merged without cancellation by col_finish_kernel<0>)
 // MODE 2: partial[b][0][k] = sum_i dy,  partial[b][1][k] = sum_i dy * xhat      (xhat = (x - mean) * rstd)
 template <int MODE>
 __global__ __launch_bounds__(256) void col_partial_kernel(const float *__restrict__ X, int64_t ldx, const float *__restrict__ DY,
@@ -55,24 +56,28 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float *__restric
     const int r0 = blockIdx.x * STAT_ROWS, r1 = min(n, r0 + STAT_ROWS);
     for (int k = threadIdx.x; k < d; k += blockDim.x) {
         float a = 0.f, b = 0.f;
-        const float m = MODE >= 1 ? mean[k] : 0.f, rs = MODE == 2 ? rstd[k] : 0.f;
-        for (int i = r0; i < r1; ++i) {
-            const float x = X[(size_t)i * ldx + k];
-            if (MODE == 0) a += x;
-            if (MODE == 1) a += (x - m) * (x - m);
-            if (MODE == 2) {
+        if (MODE == 0) {
+            for (int i = r0; i < r1; ++i) a += X[(size_t)i * ldx + k];
+            a /= (float)(r1 - r0);
+            for (int i = r0; i < r1; ++i) {
+                const float dx = X[(size_t)i * ldx + k] - a;
+                b += dx * dx;
+            }
+        } else {
+            const float m = mean[k], rs = rstd[k];
+            for (int i = r0; i < r1; ++i) {
                 const float dy = DY[(size_t)i * lddy + k];
                 a += dy;
-                b += dy * ((x - m) * rs);
+                b += dy * ((X[(size_t)i * ldx + k] - m) * rs);
             }
         }
         partial[((size_t)blockIdx.x * 2 + 0) * d + k] = a;
-        if (MODE == 2) partial[((size_t)blockIdx.x * 2 + 1) * d + k] = b;
+        partial[((size_t)blockIdx.x * 2 + 1) * d + k] = b;
     }
 }
 
-// finish in double: STEP 0 -> mean;  STEP 1 -> rstd (+ running statistics);  STEP 2 -> this call's (dbias, dweight)
-// into saved[2..3] and accumulated into the parameter gradients
+// finish in double: STEP 0 -> mean and rstd of all n rows from the per-block (mean, M2) pairs (+ running statistics);
+// STEP 2 -> this call's (dbias, dweight) into saved[2..3] and accumulated into the parameter gradients
 template <int STEP>
 __global__ __launch_bounds__(256) void col_finish_kernel(const float *__restrict__ partial, int blocks, int n, int d, float eps,
                                                          float momentum, float *__restrict__ saved, float *__restrict__ run_mean,
@@ -82,20 +87,27 @@ __global__ __launch_bounds__(256) void col_finish_kernel(const float *__restrict
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= d) return;
     double a = 0.0, b = 0.0;
-    for (int p = 0; p < blocks; ++p) {
-        a += partial[((size_t)p * 2 + 0) * d + k];
-        if (STEP == 2) b += partial[((size_t)p * 2 + 1) * d + k];
-    }
     if (STEP == 0) {
-        saved[k] = (float)(a / n);
-    } else if (STEP == 1) {
-        const double var = a / n;                                   // biased: what normalises the batch
+        // parallel-variance merge: mean = sum n_b mean_b / n,  M2 = sum [M2_b + n_b (mean_b - mean)^2]
+        for (int p = 0; p < blocks; ++p)
+            a += (double)partial[((size_t)p * 2 + 0) * d + k] * (double)min(STAT_ROWS, n - p * STAT_ROWS);
+        const double mean = a / n;
+        for (int p = 0; p < blocks; ++p) {
+            const double dm = (double)partial[((size_t)p * 2 + 0) * d + k] - mean;
+            b += (double)partial[((size_t)p * 2 + 1) * d + k] + dm * dm * (double)min(STAT_ROWS, n - p * STAT_ROWS);
+        }
+        saved[k] = (float)mean;
+        const double var = b / n;                                   // biased: what normalises the batch
         saved[d + k] = (float)(1.0 / sqrt(var + (double)eps));
         if (run_mean) {                                             // running statistics use the unbiased variance
             run_mean[k] += momentum * (saved[k] - run_mean[k]);
             run_var[k] += momentum * ((float)(var * n / (n > 1 ? n - 1 : 1)) - run_var[k]);
         }
     } else {
+        for (int p = 0; p < blocks; ++p) {
+            a += partial[((size_t)p * 2 + 0) * d + k];
+            b += partial[((size_t)p * 2 + 1) * d + k];
+        }
         saved[2 * d + k] = (float)a;
         saved[3 * d + k] = (float)b;
         d_bias[k] += (float)a;
@@ -119,41 +131,83 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
 // dx = weight * rstd * (dy - dbias/n - xhat * dweight/n)   (or dx = dy without batch-norm), then scattered into the
 // token table gradient: sum -> every token of the row, mean -> scaled by 1/(len + 1e-12), max -> the first token that
 // attains the maximum of its column.  Token 0 (padding_idx) receives nothing.
-__global__ __launch_bounds__(128) void pool_backward_kernel(const float *__restrict__ W, int d, const int32_t *__restrict__ tokens,
+// One workgroup takes POOL_BWD_ROWS rows, one thread per column.  The reference's token ids are frequency-ranked
+// (index_mapper.py:95-108 writes the maps sorted by count; BOS = 2 and EOS = 3 sit in every row), so the first
+// HOT_TOKENS ids would take thousands of same-address atomics per step: their rows are accumulated in LDS (a thread
+// owns its column, so plain read-modify-write) and flushed with one atomic per touched (token, column) per workgroup.
+constexpr int POOL_BWD_ROWS = 16, HOT_TOKENS = 32, POOL_MAX_LEN = 64;
+
+__global__ __launch_bounds__(256) void pool_backward_kernel(const float *__restrict__ W, int d, const int32_t *__restrict__ tokens,
                                                             int L, const int32_t *__restrict__ ids, int first_id, int pool,
                                                             const float *__restrict__ X, int64_t ldx,
                                                             const float *__restrict__ DY, int64_t lddy, int n,
                                                             const float *__restrict__ saved, const float *__restrict__ weight,
                                                             float *__restrict__ dW)
 {
-    const int i = blockIdx.x;
-    const int32_t *tok = tokens + (size_t)row_id(ids, first_id, i) * L;
-    float inv = 1.f;
-    if (pool == POOL_MEAN) {
+    extern __shared__ float hot[];                      // [HOT_TOKENS][d]
+    __shared__ uint32_t hot_seen;
+    __shared__ int32_t toks[POOL_BWD_ROWS][POOL_MAX_LEN];
+    __shared__ float inv_len[POOL_BWD_ROWS];
+    const int r0 = blockIdx.x * POOL_BWD_ROWS, nr = min(n, r0 + POOL_BWD_ROWS) - r0;
+    for (int i = threadIdx.x; i < HOT_TOKENS * d; i += blockDim.x) hot[i] = 0.f;
+    for (int i = threadIdx.x; i < nr * L; i += blockDim.x)
+        toks[i / L][i % L] = tokens[(size_t)row_id(ids, first_id, r0 + i / L) * L + i % L];
+    if (threadIdx.x == 0) hot_seen = 0;
+    __syncthreads();
+    if (threadIdx.x < nr) {
         int len = 0;
-        for (int t = 0; t < L; ++t) len += tok[t] > 0;
-        inv = 1.f / ((float)len + 1e-12f);
+        for (int t = 0; t < L; ++t) len += toks[threadIdx.x][t] > 0;
+        inv_len[threadIdx.x] = pool == POOL_MEAN ? 1.f / ((float)len + 1e-12f) : 1.f;
     }
+    __syncthreads();
     const float inv_n = 1.f / (float)n;
+    uint32_t seen = 0;
     for (int k = threadIdx.x; k < d; k += blockDim.x) {
-        float g = DY[(size_t)i * lddy + k];
+        // all of this column's gradients first (independent loads in flight), then the scatter
+        float g[POOL_BWD_ROWS];
+#pragma unroll
+        for (int r = 0; r < POOL_BWD_ROWS; ++r) g[r] = r < nr ? DY[(size_t)(r0 + r) * lddy + k] : 0.f;
         if (saved) {
-            const float m = saved[k], rs = saved[d + k], db = saved[2 * d + k], dw = saved[3 * d + k];
-            const float xhat = (X[(size_t)i * ldx + k] - m) * rs;
-            g = weight[k] * rs * (g - db * inv_n - xhat * dw * inv_n);
-        }
-        if (pool == POOL_MAX) {
-            int best = 0;
-            float bw = -INFINITY;
-            for (int t = 0; t < L; ++t) {
-                const float w = W[(size_t)tok[t] * d + k];
-                if (w > bw) { bw = w; best = t; }
+            const float m = saved[k], rs = saved[d + k], db = saved[2 * d + k], dw = saved[3 * d + k], wk = weight[k];
+#pragma unroll
+            for (int r = 0; r < POOL_BWD_ROWS; ++r) {
+                const float x = r < nr ? X[(size_t)(r0 + r) * ldx + k] : 0.f;
+                g[r] = wk * rs * (g[r] - db * inv_n - (x - m) * rs * dw * inv_n);
             }
-            if (tok[best] != 0) atomicAdd(dW + (size_t)tok[best] * d + k, g);
-        } else {
-            g *= inv;
-            for (int t = 0; t < L; ++t)
-                if (tok[t] != 0) atomicAdd(dW + (size_t)tok[t] * d + k, g);
+        }
+#pragma unroll
+        for (int r = 0; r < POOL_BWD_ROWS; ++r) {
+            if (r >= nr) continue;
+            if (pool == POOL_MAX) {
+                int best = 0;
+                float bw = -INFINITY;
+                for (int t = 0; t < L; ++t) {
+                    const float w = W[(size_t)toks[r][t] * d + k];
+                    if (w > bw) { bw = w; best = t; }
+                }
+                const int tk = toks[r][best];
+                if (tk == 0) continue;
+                if (tk < HOT_TOKENS) { hot[tk * d + k] += g[r]; seen |= 1u << tk; }
+                else atomicAdd(dW + (size_t)tk * d + k, g[r]);
+            } else {
+                const float gg = g[r] * inv_len[r];
+                for (int t = 0; t < L; ++t) {
+                    const int tk = toks[r][t];
+                    if (tk == 0) continue;
+                    if (tk < HOT_TOKENS) { hot[tk * d + k] += gg; seen |= 1u << tk; }
+                    else atomicAdd(dW + (size_t)tk * d + k, gg);
+                }
+            }
+        }
+    }
+    if (seen) atomicOr(&hot_seen, seen);
+    __syncthreads();
+    const uint32_t all = hot_seen;
+    for (int tk = 1; tk < HOT_TOKENS; ++tk) {
+        if (!(all >> tk & 1u)) continue;
+        for (int k = threadIdx.x; k < d; k += blockDim.x) {
+            const float v = hot[tk * d + k];
+            if (v != 0.f) atomicAdd(dW + (size_t)tk * d + k, v);
         }
     }
 }
@@ -180,10 +234,7 @@ hipError_t launch_bn_stats(const float *X, int64_t ldx, int n, int d, float eps,
 {
     const int blocks = (n + STAT_ROWS - 1) / STAT_ROWS, fb = (d + 255) / 256;
     hipLaunchKernelGGL(col_partial_kernel<0>, dim3(blocks), dim3(256), 0, st, X, ldx, nullptr, 0, n, d, nullptr, nullptr, partial);
-    hipLaunchKernelGGL(col_finish_kernel<0>, dim3(fb), dim3(256), 0, st, partial, blocks, n, d, eps, momentum, saved, nullptr,
-                       nullptr, nullptr, nullptr);
-    hipLaunchKernelGGL(col_partial_kernel<1>, dim3(blocks), dim3(256), 0, st, X, ldx, nullptr, 0, n, d, saved, nullptr, partial);
-    hipLaunchKernelGGL(col_finish_kernel<1>, dim3(fb), dim3(256), 0, st, partial, blocks, n, d, eps, momentum, saved, run_mean,
+    hipLaunchKernelGGL(col_finish_kernel<0>, dim3(fb), dim3(256), 0, st, partial, blocks, n, d, eps, momentum, saved, run_mean,
                        run_var, nullptr, nullptr);
     return hipGetLastError();
 }
@@ -209,8 +260,9 @@ hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, in
         hipLaunchKernelGGL(col_finish_kernel<2>, dim3(fb), dim3(256), 0, st, partial, blocks, n, d, 0.f, 0.f, saved, nullptr,
                            nullptr, d_weight, d_bias);
     }
-    hipLaunchKernelGGL(pool_backward_kernel, dim3(n), dim3(128), 0, st, W, d, tokens, L, ids, first_id, pool, X, ldx, DY, lddy, n,
-                       saved, weight, dW);
+    hipLaunchKernelGGL(pool_backward_kernel, dim3((n + POOL_BWD_ROWS - 1) / POOL_BWD_ROWS), dim3(256),
+                       sizeof(float) * HOT_TOKENS * d, st, W, d, tokens, L, ids, first_id, pool, X, ldx, DY, lddy, n, saved,
+                       weight, dW);
     return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ class DropoutSpec:
     stream: int = 0
     step: int = 0
     keep: Optional[torch.Tensor] = None
+    step_dev: Optional[torch.Tensor] = None   # int32[1] on the device: the kernels read the step from it (graph replay)
 
     def c(self) -> N.Dropout:
         d = N.Dropout()
@@ -35,6 +36,7 @@ class DropoutSpec:
         d.stream = int(self.stream) & 0xFFFFFFFF
         d.step = int(self.step) & 0xFFFFFFFF
         d.keep = self.keep.data_ptr() if (self.keep is not None and self.p > 0) else None
+        d.step_dev = self.step_dev.data_ptr() if self.step_dev is not None else None
         return d
 
 

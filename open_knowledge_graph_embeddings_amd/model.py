@@ -238,6 +238,7 @@ class LookupDistmultRelationModel(DistmultRelationScorer, LookupSimpleRelationEm
 
 class Models:
     """openkge/model.py:1052-1066: looked up with getattr(Models, args['model']) (scripts/train.py:88).
-    Only the two models of the fused path are registered; the others stay with the reference."""
+    The lookup models are registered here, the token-pooled ones by token_pooled.py (imported by the package);
+    the others stay with the reference."""
     LookupDistmultRelationModel = LookupDistmultRelationModel
     LookupComplexRelationModel = LookupComplexRelationModel

@@ -17,7 +17,7 @@ import torch
 
 from . import _native as N
 from . import hotpath as H
-from .model import ComplexRelationScorer, DistmultRelationScorer, RelationEmbedder
+from .model import ComplexRelationScorer, DistmultRelationScorer, Models, RelationEmbedder
 
 POOLS = {"sum": 0, "mean": 1, "max": 2}
 BN_EPS, BN_MOMENTUM = 1e-5, 0.1                     # torch.nn.BatchNorm1d(momentum=0.1, eps=1e-5), model.py:611-612
@@ -133,7 +133,16 @@ class TokenPooledTrainStep:
         self.engine = engine or H.HotPath(self.device)
         self.pool = PoolEngine(self.device)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.step_dev = None              # device step counter, attached by GraphedTrainStep
         self._rows = 0
+
+    def state_tensors(self):
+        out = []
+        for sl in (self.entity, self.relation):
+            out += [sl.W, sl.dW, sl.sumW]
+            if sl.bn is not None:
+                out += [sl.bn, sl.d_bn, sl.sum_bn, sl.running_mean, sl.running_var]
+        return out
 
     def _buffers(self, n_ent_rows, n_rel_rows):
         d = self.entity.d
@@ -173,12 +182,12 @@ class TokenPooledTrainStep:
         # the fused step on the virtual tables: candidates are rows 0..N-1, prefix entities follow
         ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
         p, s, t = self.dropout, self.seed, self.steps
+        DS = lambda stream: H.DropoutSpec(p, s, stream, t, step_dev=self.step_dev)      # noqa: E731
         vb = H.PrefixBatch(po_rel=ar(0, n_po) if n_po else None, po_obj=ar(N_c, N_c + n_po) if n_po else None,
                            sp_subj=ar(N_c + n_po, N_c + B) if n_sp else None, sp_rel=ar(n_po, B) if n_sp else None,
                            pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=N_c,
-                           drop_cand=H.DropoutSpec(p, s, H.STREAM_CAND, t), drop_po_ent=H.DropoutSpec(p, s, H.STREAM_PO_ENT, t),
-                           drop_sp_ent=H.DropoutSpec(p, s, H.STREAM_SP_ENT, t), drop_po_rel=H.DropoutSpec(p, s, H.STREAM_PO_REL, t),
-                           drop_sp_rel=H.DropoutSpec(p, s, H.STREAM_SP_REL, t))
+                           drop_cand=DS(H.STREAM_CAND), drop_po_ent=DS(H.STREAM_PO_ENT), drop_sp_ent=DS(H.STREAM_SP_ENT),
+                           drop_po_rel=DS(H.STREAM_PO_REL), drop_sp_rel=DS(H.STREAM_SP_REL))
         self.engine.forward_backward(EVt[:N_c + B], RVt[:B], self.scorer, vb, dEV[:N_c + B], dRV[:B], loss=self.loss,
                                      label_smoothing=self.label_smoothing, normalizer=normalizer, loss_out=self.loss_out,
                                      scores=scores, grads_zero=True)
@@ -351,3 +360,8 @@ class UnigramPoolingComplexRelationModel(ComplexRelationScorer, UnigramPoolingRe
 class UnigramPoolingDistmultRelationModel(DistmultRelationScorer, UnigramPoolingRelationEmbedder):
     def __init__(self, **kwargs):
         super().__init__(**kwargs)
+
+
+# registered like the reference's (model.py:1052-1066): getattr(Models, args["model"])
+Models.UnigramPoolingComplexRelationModel = UnigramPoolingComplexRelationModel
+Models.UnigramPoolingDistmultRelationModel = UnigramPoolingDistmultRelationModel

@@ -27,18 +27,23 @@ class FusedTrainStep:
         self.dE, self.dR = torch.zeros_like(E), torch.zeros_like(R)       # dense .grad (model_config.sparse False)
         self.sumE, self.sumR = torch.zeros_like(E), torch.zeros_like(R)   # Adagrad state 'sum' (init 0)
         self.steps = 0
+        self.step_dev = None              # device step counter, attached by GraphedTrainStep
         self._grads_zero = True           # fresh buffers; kept true by the zero_grad fused into Adagrad
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=E.device)
+
+    def state_tensors(self):
+        """every tensor a step mutates (GraphedTrainStep snapshots them around its warm-up)"""
+        return [self.E, self.R, self.dE, self.dR, self.sumE, self.sumR]
 
     def _set_dropout(self, batch: H.PrefixBatch, training=True):
         pe = self.input_dropout if training else 0.0
         pr = self.relation_input_dropout if training else 0.0
-        s, t = self.seed, self.steps
-        batch.drop_cand = H.DropoutSpec(pe, s, H.STREAM_CAND, t)
-        batch.drop_po_ent = H.DropoutSpec(pe, s, H.STREAM_PO_ENT, t)
-        batch.drop_sp_ent = H.DropoutSpec(pe, s, H.STREAM_SP_ENT, t)
-        batch.drop_po_rel = H.DropoutSpec(pr, s, H.STREAM_PO_REL, t)
-        batch.drop_sp_rel = H.DropoutSpec(pr, s, H.STREAM_SP_REL, t)
+        s, t, sd = self.seed, self.steps, self.step_dev
+        batch.drop_cand = H.DropoutSpec(pe, s, H.STREAM_CAND, t, step_dev=sd)
+        batch.drop_po_ent = H.DropoutSpec(pe, s, H.STREAM_PO_ENT, t, step_dev=sd)
+        batch.drop_sp_ent = H.DropoutSpec(pe, s, H.STREAM_SP_ENT, t, step_dev=sd)
+        batch.drop_po_rel = H.DropoutSpec(pr, s, H.STREAM_PO_REL, t, step_dev=sd)
+        batch.drop_sp_rel = H.DropoutSpec(pr, s, H.STREAM_SP_REL, t, step_dev=sd)
 
     def forward_backward(self, batch: H.PrefixBatch, normalizer=None):
         """trainer.py:206-234.  Returns the summed loss (device double[1], valid after stream sync)."""
@@ -59,3 +64,73 @@ class FusedTrainStep:
         self.optimizer_step()
         self._grads_zero = True
         return loss
+
+
+class GraphedTrainStep:
+    """Replays one training step as a HIP graph (torch.cuda.CUDAGraph records the library's launches on the capture
+    stream): a step is ~5 kernels of 5-80 us for the lookup models and ~50 for the token-pooled ones, so the Python /
+    ctypes launch path, not the GPU, bounds small steps.  Shapes are fixed at capture: n_po, n_sp, the candidate
+    count and a CAPACITY for the positives -- shorter lists are padded with (row -1, col INT32_MAX), which sort
+    behind every candidate tile and are skipped by the kernels.  The dropout step counter lives on the device and is
+    incremented inside the graph, so every replay draws new masks (okge_dropout.step_dev).
+
+    `inner` is a FusedTrainStep or a TokenPooledTrainStep (anything with .step(batch), .device-resident state and a
+    `step_dev` attribute)."""
+
+    PAD_COL = 2 ** 31 - 1
+
+    def __init__(self, inner, example: H.PrefixBatch, pos_capacity, normalizer=None):
+        self.inner = inner
+        dev = example.pos_row.device
+        self.device = dev
+        self.pos_capacity = int(pos_capacity)
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=dev)      # noqa: E731
+        self.static = H.PrefixBatch(
+            po_rel=i32(example.n_po) if example.n_po else None, po_obj=i32(example.n_po) if example.n_po else None,
+            sp_subj=i32(example.n_sp) if example.n_sp else None, sp_rel=i32(example.n_sp) if example.n_sp else None,
+            pos_row=i32(self.pos_capacity), pos_col=i32(self.pos_capacity),
+            cand_ids=None if example.cand_ids is None else i32(example.cand_ids.numel()),
+            cand_first=example.cand_first, n_cand=example.n_cand, cand_unique=example.cand_unique)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        inner.step_dev = self.counter
+        self.normalizer = normalizer
+        self._load(example)
+        state = inner.state_tensors()
+        saved, steps0 = [t.clone() for t in state], inner.steps
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                       # warm-up outside capture: workspaces get allocated
+            for _ in range(2):
+                inner.step(self.static, normalizer)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        for t, s0 in zip(state, saved):                     # the warm-up steps must not count as training
+            t.copy_(s0)
+        inner.steps = steps0
+        self.counter.fill_(steps0)
+        del saved
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.counter += 1
+            self.loss = inner.step(self.static, normalizer)
+
+    def _load(self, b: H.PrefixBatch):
+        s = self.static
+        if b.n_po != s.n_po or b.n_sp != s.n_sp or b.n_candidates != s.n_candidates or b.nnz > self.pos_capacity:
+            raise ValueError("batch shape differs from the captured one (n_po, n_sp, candidates fixed; positives <= capacity)")
+        for name in ("po_rel", "po_obj", "sp_subj", "sp_rel", "cand_ids"):
+            dst, src = getattr(s, name), getattr(b, name)
+            if dst is not None:
+                dst.copy_(src.reshape(-1), non_blocking=True)
+        n = b.nnz
+        s.pos_row[:n].copy_(b.pos_row, non_blocking=True)
+        s.pos_col[:n].copy_(b.pos_col, non_blocking=True)
+        if n < self.pos_capacity:
+            s.pos_row[n:].fill_(-1)
+            s.pos_col[n:].fill_(self.PAD_COL)
+
+    def step(self, batch: H.PrefixBatch):
+        """Copies the batch into the captured buffers and replays; returns the device loss (double[1])."""
+        self._load(batch)
+        self.graph.replay()
+        return self.loss

@@ -387,3 +387,31 @@ def test_full_size_fb15k237_shape(hp):
     b2 = make_batch(z, cand[sub], n_ent)
     out_sub = hp.score(Et, Rt, "complex", b2).cpu().numpy()
     np.testing.assert_array_equal(out_sub, out[:, sub])
+
+
+# --------------------------------------------------------------------------------------- HIP-graph replay
+def test_graphed_step_equals_plain_step(hp):
+    """GraphedTrainStep (captured once, replayed with padded positives and a device-side dropout counter) walks the
+    same trajectory as FusedTrainStep called from Python: same masks, same losses, same tables."""
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep, GraphedTrainStep
+    n_ent, n_rel, d, n_po, n_sp = 1200, 20, 200, 70, 58
+    problems = [random_problem(500 + i, n_ent, n_rel, d, n_po, n_sp, max_pos=2 + 2 * i) for i in range(4)]
+    E, R = problems[0][0], problems[0][1]
+    batches = [make_batch(z, cand, n_ent, labels=y) for _, _, z, cand, y in problems]
+    assert len({b.nnz for b in batches}) > 1                       # the positives' count really varies
+    plain = FusedTrainStep(dev(E.copy()), dev(R.copy()), "complex", lr=0.3, input_dropout=0.4, seed=99)
+    inner = FusedTrainStep(dev(E.copy()), dev(R.copy()), "complex", lr=0.3, input_dropout=0.4, seed=99)
+    graphed = GraphedTrainStep(inner, batches[0], pos_capacity=max(b.nnz for b in batches) + 13)
+    np.testing.assert_array_equal(inner.E.cpu().numpy(), E)        # the capture warm-up left no trace
+    for i in range(6):
+        b = batches[i % 4]
+        lp = float(plain.step(b)[0])
+        lg = float(graphed.step(b)[0])
+        # the prefix rows' gradients are scattered with float atomics (order varies run to run): equal to ~1e-7
+        assert abs(lp - lg) <= 1e-7 * abs(lp), (i, lp, lg)
+    for a, b2 in ((inner.E, plain.E), (inner.R, plain.R)):       # Adagrad amplifies that noise on a few tiny gradients
+        a, b2 = a.cpu().numpy(), b2.cpu().numpy()
+        assert np.isclose(a, b2, rtol=1e-4, atol=1e-5).mean() > 0.9999 and np.abs(a - b2).max() < 1e-3
+    with pytest.raises(ValueError):
+        graphed.step(make_batch(*[random_problem(9, n_ent, n_rel, d, n_po + 1, n_sp)[i] for i in (2, 3)], n_ent,
+                                labels=random_problem(9, n_ent, n_rel, d, n_po + 1, n_sp)[4]))

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""One-GPU timings of the other BASELINE.json configurations (the bench.py line is configs[1] = S-FB):
+
+  S-DM        configs[2]  DistMult d=512, B=512, batch-shared sampled list N=10 000 (unique ids)
+  S-OLP-shard configs[3]  one GPU's share of the OLPBENCH-shaped run: 312 500 local candidates, B=4096, d=256
+  S-OLP-tok   configs[4]  token-pooled ComplEx d=256, B=4096, batch-shared N=8192, 10 tokens per entity, batch-norm
+
+Prints one JSON object per workload (ms/step, per-kernel averages from the library's HIP-event timers)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from open_knowledge_graph_embeddings_amd import hotpath as H  # noqa: E402
+from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep  # noqa: E402
+
+
+def positives(rng, B, N, per_row=2):
+    rows = np.repeat(np.arange(B, dtype=np.int64), per_row)
+    cols = rng.integers(0, N, rows.shape[0])
+    key = np.unique(cols * B + rows)
+    return (key % B).astype(np.int32), (key // B).astype(np.int32)
+
+
+def run(name, step, batches, steps=30, warmup=5):
+    for i in range(warmup):
+        step.step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step.step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    eng = step.engine
+    eng.timing(True)
+    for i in range(10):
+        step.step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    per = {k: round(v[0] / v[1] * 1e3, 2) for k, v in eng.timing_collect().items()}
+    eng.timing(False)
+    b = batches[0]
+    out = {"workload": name, "ms_per_step": round(ms, 4), "prefixes_per_s": round(b.B / ms * 1e3), "kernels_us": per}
+    print(json.dumps(out), flush=True)
+    return out
+
+
+def main():
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
+    which = sys.argv[1:] or ["S-DM", "S-OLP-shard", "S-OLP-tok"]
+    if "S-DM" in which:
+        n_ent, n_rel, d, B, N = 14543, 239, 512, 512, 10000
+        E, R = (rng.standard_normal((n, d), dtype=np.float32) * 0.1 for n in (n_ent, n_rel))
+        step = FusedTrainStep(t(E), t(R), "distmult", lr=0.1, input_dropout=0.2, seed=1)
+        batches = []
+        for _ in range(4):
+            pr, pc = positives(rng, B, N)
+            batches.append(H.PrefixBatch(po_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)),
+                                         sp_subj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)),
+                                         pos_row=t(pr), pos_col=t(pc), cand_ids=t(rng.permutation(np.arange(2, n_ent))[:N].astype(np.int32)),
+                                         cand_unique=True))
+        run("S-DM", step, batches)
+        del step, batches
+    if "S-OLP-shard" in which:
+        n_ent, n_rel, d, B = 312_500 + 2, 100_000, 256, 4096
+        E = torch.randn((n_ent, d), device=dev) * 0.1
+        R = torch.randn((n_rel, d), device=dev) * 0.1
+        step = FusedTrainStep(E, R, "complex", lr=0.1, seed=1)
+        batches = []
+        for _ in range(2):
+            pr, pc = positives(rng, B, n_ent - 2, per_row=1)
+            batches.append(H.PrefixBatch(po_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)),
+                                         sp_subj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)),
+                                         pos_row=t(pr), pos_col=t(pc), cand_first=2, n_cand=n_ent - 2))
+        out = run("S-OLP-shard", step, batches, steps=5, warmup=2)
+        flops = 6.0 * B * (n_ent - 2) * d
+        print(json.dumps({"S-OLP-shard step TFLOP/s (6BNd)": round(flops / out["ms_per_step"] / 1e9, 1)}), flush=True)
+        del step, batches, E, R
+    if "S-OLP-tok" in which:
+        from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+        n_ent, n_rel, d, B, N, L, vt_e, vt_r = 2_500_000, 100_000, 256, 4096, 8192, 10, 200_000, 50_000
+
+        def tokens(n, vocab):
+            lens = np.minimum(1 + rng.poisson(2, n), L - 2)
+            m = np.zeros((n, L), np.int32)
+            m[:, 0] = 2
+            body = (4 + (rng.zipf(1.2, (n, L)) - 1) % (vocab - 4)).astype(np.int32)
+            for j in range(1, L):
+                m[:, j] = np.where(j <= lens, body[:, j], np.where(j == lens + 1, 3, 0))
+            return t(m)
+        ent = TokenSlot(torch.randn((vt_e, d), device=dev) * 0.1, tokens(n_ent, vt_e), "sum", True)
+        rel = TokenSlot(torch.randn((vt_r, d), device=dev) * 0.1, tokens(n_rel, vt_r), "sum", True)
+        step = TokenPooledTrainStep(ent, rel, "complex", lr=0.1, dropout=0.1, seed=1)
+        batches = []
+        for _ in range(2):
+            pr, pc = positives(rng, B, N, per_row=1)
+            batches.append(H.PrefixBatch(po_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)),
+                                         sp_subj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)),
+                                         pos_row=t(pr), pos_col=t(pc), cand_ids=t(rng.choice(n_ent - 2, N, replace=False).astype(np.int32) + 2)))
+        run("S-OLP-tok", step, batches, steps=20, warmup=3)
+        # the same step replayed as a HIP graph (~50 launches collapse into one)
+        from open_knowledge_graph_embeddings_amd.train_step import GraphedTrainStep
+        g = GraphedTrainStep(step, batches[0], pos_capacity=max(b.nnz for b in batches))
+        for i in range(3):
+            g.step(batches[i % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(20):
+            g.step(batches[i % 2])
+        torch.cuda.synchronize()
+        print(json.dumps({"workload": "S-OLP-tok (HIP graph replay)", "ms_per_step": round(1e3 * (time.perf_counter() - t0) / 20, 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
