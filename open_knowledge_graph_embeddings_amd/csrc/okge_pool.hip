@@ -84,30 +84,46 @@ __global__ __launch_bounds__(256) void col_finish_kernel(const float *__restrict
                                                          float *__restrict__ run_var, float *__restrict__ d_weight,
                                                          float *__restrict__ d_bias)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= d) return;
+    // 64 columns per workgroup, 4 threads per column each folding a quarter of the row-block partials
+    __shared__ double red[2][4][64];
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6, k = blockIdx.x * 64 + c;
+    const bool live = k < d;
     double a = 0.0, b = 0.0;
     if (STEP == 0) {
         // parallel-variance merge: mean = sum n_b mean_b / n,  M2 = sum [M2_b + n_b (mean_b - mean)^2]
-        for (int p = 0; p < blocks; ++p)
-            a += (double)partial[((size_t)p * 2 + 0) * d + k] * (double)min(STAT_ROWS, n - p * STAT_ROWS);
-        const double mean = a / n;
-        for (int p = 0; p < blocks; ++p) {
-            const double dm = (double)partial[((size_t)p * 2 + 0) * d + k] - mean;
-            b += (double)partial[((size_t)p * 2 + 1) * d + k] + dm * dm * (double)min(STAT_ROWS, n - p * STAT_ROWS);
-        }
+        if (live)
+            for (int p = grp; p < blocks; p += 4)
+                a += (double)partial[((size_t)p * 2 + 0) * d + k] * (double)min(STAT_ROWS, n - p * STAT_ROWS);
+        red[0][grp][c] = a;
+        __syncthreads();
+        const double mean = (red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]) / n;
+        if (live)
+            for (int p = grp; p < blocks; p += 4) {
+                const double dm = (double)partial[((size_t)p * 2 + 0) * d + k] - mean;
+                b += (double)partial[((size_t)p * 2 + 1) * d + k] + dm * dm * (double)min(STAT_ROWS, n - p * STAT_ROWS);
+            }
+        red[1][grp][c] = b;
+        __syncthreads();
+        if (!live || grp != 0) return;
+        const double var = (red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) / n;   // biased: normalises the batch
         saved[k] = (float)mean;
-        const double var = b / n;                                   // biased: what normalises the batch
         saved[d + k] = (float)(1.0 / sqrt(var + (double)eps));
         if (run_mean) {                                             // running statistics use the unbiased variance
-            run_mean[k] += momentum * (saved[k] - run_mean[k]);
+            run_mean[k] += momentum * ((float)mean - run_mean[k]);
             run_var[k] += momentum * ((float)(var * n / (n > 1 ? n - 1 : 1)) - run_var[k]);
         }
     } else {
-        for (int p = 0; p < blocks; ++p) {
-            a += partial[((size_t)p * 2 + 0) * d + k];
-            b += partial[((size_t)p * 2 + 1) * d + k];
-        }
+        if (live)
+            for (int p = grp; p < blocks; p += 4) {
+                a += partial[((size_t)p * 2 + 0) * d + k];
+                b += partial[((size_t)p * 2 + 1) * d + k];
+            }
+        red[0][grp][c] = a;
+        red[1][grp][c] = b;
+        __syncthreads();
+        if (!live || grp != 0) return;
+        a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
         saved[2 * d + k] = (float)a;
         saved[3 * d + k] = (float)b;
         d_bias[k] += (float)a;
@@ -232,7 +248,7 @@ hipError_t launch_pool_rows(const float *W, int d, const int32_t *tokens, int L,
 hipError_t launch_bn_stats(const float *X, int64_t ldx, int n, int d, float eps, float momentum, float *saved,
                            float *run_mean, float *run_var, float *partial, hipStream_t st)
 {
-    const int blocks = (n + STAT_ROWS - 1) / STAT_ROWS, fb = (d + 255) / 256;
+    const int blocks = (n + STAT_ROWS - 1) / STAT_ROWS, fb = (d + 63) / 64;
     hipLaunchKernelGGL(col_partial_kernel<0>, dim3(blocks), dim3(256), 0, st, X, ldx, nullptr, 0, n, d, nullptr, nullptr, partial);
     hipLaunchKernelGGL(col_finish_kernel<0>, dim3(fb), dim3(256), 0, st, partial, blocks, n, d, eps, momentum, saved, run_mean,
                        run_var, nullptr, nullptr);
@@ -255,7 +271,7 @@ hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, in
 {
     if (n <= 0) return hipSuccess;
     if (saved) {
-        const int blocks = (n + STAT_ROWS - 1) / STAT_ROWS, fb = (d + 255) / 256;
+        const int blocks = (n + STAT_ROWS - 1) / STAT_ROWS, fb = (d + 63) / 64;
         hipLaunchKernelGGL(col_partial_kernel<2>, dim3(blocks), dim3(256), 0, st, X, ldx, DY, lddy, n, d, saved, saved + d, partial);
         hipLaunchKernelGGL(col_finish_kernel<2>, dim3(fb), dim3(256), 0, st, partial, blocks, n, d, 0.f, 0.f, saved, nullptr,
                            nullptr, d_weight, d_bias);
