@@ -153,9 +153,9 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.b_split = (g.Bpad + g.b_per_block - 1) / g.b_per_block;
     // dQ kernel: (batch block, candidate range) workgroups, two per CU (measured: 512 beats 256 workgroups)
     int ns = std::max(1, 512 / bblks);
+    if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
     ns = env_int("OKGE_DQ_SPLIT", ns);
     ns = std::max(1, std::min(ns, g.tiles));
-    if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
     g.nsplit = ns;
     size_t off = 0;
     g.off_Q = off;     off += align_up((size_t)g.Bpad * g.ldq * sizeof(float), 256);
