@@ -174,7 +174,7 @@ def main():
         triples += n_pos[i % N_BATCHES]
     barrier()
     elapsed = time.perf_counter() - t0
-    loss_last = float(step.loss_out.item())
+    loss_last = float((step.reduce_loss() if sharded else step.loss_out).item())
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -151,8 +151,11 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
  * (the reference has no counterpart: its only multi-device mechanism is nn.DataParallel, trainer.py:143-145.)
  * Rank r holds entity rows [ent_lo, ent_hi) (okge_tables.E points at its slice, n_ent = ent_hi - ent_lo) plus
  * the whole relation table.  One step on every rank, with two small all-reduces supplied by the caller (RCCL):
- *   1. okge_encode_queries  : query rows (and the masked prefix entity rows) of the prefixes whose entity this
- *                             rank owns, zeros elsewhere            -> all-reduce(sum) of Q and ent_rows
+ *   1. okge_encode_queries  : the masked prefix entity rows (Q == NULL) of the prefixes whose entity this rank
+ *                             owns, zeros elsewhere                 -> all-reduce(sum) of ent_rows  (B x d floats)
+ *      okge_fold_queries    : every rank folds them with its replicated relation rows into the query block
+ *                             (passing Q to okge_encode_queries instead computes the owned query rows at once;
+ *                             Q would then need its own all-reduce)
  *   2. okge_train_tiles     : score/loss/dCand against the LOCAL candidates, dE of the local rows, partial dQ
  *                                                                   -> all-reduce(sum) of dQ (and of the loss)
  *   3. okge_prefix_backward : chain rule; entity gradients scattered by the owner, relation gradients formed
@@ -175,6 +178,8 @@ int32_t okge_query_rows(int32_t B);    /* rows those blocks must have (B rounded
 
 int okge_encode_queries(const okge_tables *t, const okge_shard *shard, const okge_prefix_batch *batch,
                         float *Q, int64_t ldq, float *ent_rows, void *stream);
+int okge_fold_queries(const okge_tables *t, const okge_prefix_batch *batch, const float *ent_rows, int64_t ldq,
+                      float *Q, void *stream);
 int okge_train_tiles(const okge_tables *t, const okge_shard *shard, const float *Q, int64_t ldq, int32_t B,
                      const okge_candidates *local_cand, const okge_positives *pos, int32_t loss_kind,
                      float label_smoothing, double normalizer, int32_t n_cand_global, int32_t flags,

@@ -115,7 +115,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Geometry {
     int    B, N, d, Bpad, D16, KB, LDK, ldq, ldg, tiles, b_split, b_per_block, nsplit;
     int    tile_w, ktiles;      // fused train kernel: tile width (32 or 64 candidates) and tile count
-    size_t off_Q, off_tptr, off_GT, off_Cm, off_slab, off_loss, off_stats, off_lse, off_ysum, total;
+    size_t off_Q, off_tptr, off_GT, off_Cm, off_slab, off_loss, off_stats, off_lse, off_ysum, off_dcs, total;
 };
 
 int env_int(const char *name, int dflt)
@@ -167,6 +167,7 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.off_stats = off; off += align_up((size_t)2 * g.ktiles * g.Bpad * 2 * sizeof(float), 256);
     g.off_lse = off;   off += align_up((size_t)g.Bpad * sizeof(float), 256);
     g.off_ysum = off;  off += align_up((size_t)g.Bpad * sizeof(float), 256);
+    g.off_dcs = off;   off += g.b_split > 1 ? align_up((size_t)g.b_split * g.ktiles * 32 * g.D16 * sizeof(float), 256) : 0;
     g.total = off;
     return true;
 }
@@ -301,6 +302,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     a.G = reinterpret_cast<float *>(ws + g.off_GT);
     a.Cm = reinterpret_cast<float *>(ws + g.off_Cm);
     a.dE = dE;
+    a.dC_slab = g.b_split > 1 ? reinterpret_cast<float *>(ws + g.off_dcs) : nullptr;
     a.loss_partial = reinterpret_cast<double *>(ws + g.off_loss);
     a.loss_kind = loss_kind;
     a.inv_norm = (float)(1.0 / normalizer);
@@ -350,6 +352,12 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         e = launch_fused32(mode, a, g.ktiles, g.b_split, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
     }
+    if (g.b_split > 1 && !loss_only) {
+        ScopedTimer tm("dc_reduce", st);
+        e = launch_dc_reduce(a.dC_slab, g.b_split, g.ktiles * 32, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
+                             a.grads_zero, dE, st);
+        if (e != hipSuccess) return fail_hip(e, "dc_reduce");
+    }
     if (loss_only) {
         ScopedTimer tm("loss_reduce", st);
         e = launch_loss_reduce(a.loss_partial, g.ktiles * g.b_split, loss_out, st);
@@ -368,14 +376,10 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         if (e != hipSuccess) return fail_hip(e, "dq_kernel");
     }
     if (dq_out) {
-        {
-            ScopedTimer tm("slab_reduce", st);
-            e = launch_slab_reduce(q.slab, g.nsplit, (int64_t)g.Bpad * g.ldq, dq_out, st);
-            if (e != hipSuccess) return fail_hip(e, "slab_reduce");
-        }
-        ScopedTimer tm("loss_reduce", st);
-        e = launch_loss_reduce(a.loss_partial, g.ktiles * g.b_split, loss_out, st);
-        if (e != hipSuccess) return fail_hip(e, "loss_reduce");
+        ScopedTimer tm("slab_reduce", st);          // + the deterministic loss reduction (one extra workgroup)
+        e = launch_slab_reduce(q.slab, g.nsplit, (int64_t)g.Bpad * g.ldq, dq_out, a.loss_partial, g.ktiles * g.b_split,
+                               loss_out, st);
+        if (e != hipSuccess) return fail_hip(e, "slab_reduce");
         return OKGE_OK;
     }
     {
@@ -426,7 +430,7 @@ int okge_encode_queries(const okge_tables *t, const okge_shard *sh, const okge_p
     none.n = 1; none.first_id = 0;
     if (int rc = check_common(t, batch, &none)) return rc;
     if (int rc = check_shard(t, sh)) return rc;
-    if (!Q || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad query block");
+    if ((!Q && !ent_rows) || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad query block");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const PrefixDev p = to_dev(*batch, sh);
     ScopedTimer tm("encode_queries", st);
@@ -434,6 +438,23 @@ int okge_encode_queries(const okge_tables *t, const okge_shard *sh, const okge_p
                                          okge_query_rows(batch->n_po + batch->n_sp), ent_rows, nullptr, 0, nullptr, 0,
                                          NT, 0, st);
     if (e != hipSuccess) return fail_hip(e, "encode_queries");
+    return OKGE_OK;
+}
+
+int okge_fold_queries(const okge_tables *t, const okge_prefix_batch *batch, const float *ent_rows, int64_t ldq, float *Q,
+                      void *stream)
+{
+    okge_candidates none;
+    std::memset(&none, 0, sizeof(none));
+    none.n = 1; none.first_id = 0;
+    if (int rc = check_common(t, batch, &none)) return rc;
+    if (!ent_rows || !Q || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad query block");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PrefixDev p = to_dev(*batch);
+    ScopedTimer tm("fold_queries", st);
+    hipError_t e = launch_fold_queries(t->R, t->d, t->scorer, p, ent_rows, Q, (int)ldq,
+                                       okge_query_rows(batch->n_po + batch->n_sp), st);
+    if (e != hipSuccess) return fail_hip(e, "fold_queries");
     return OKGE_OK;
 }
 

@@ -27,6 +27,7 @@ struct FusedArgs {
     float         *G;          // [Bpad][ldg]  dLoss/dX / normalizer, row-major, ldg = 64 * tiles
     float         *Cm;         // [64 * tiles][16*KB]  masked (dropped-out) candidate rows, for dq_kernel
     float         *dE;
+    float         *dC_slab;    // [gridDim.y][32 * ktiles][16*KB] partial candidate gradients when the batch is split over blockIdx.y
     double        *loss_partial;
     float         *X;          // score mode
     float         *stats;      // stats mode: float2 [tiles][Bpad]
@@ -62,7 +63,10 @@ hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
                                  int tiles, int tile_w, int cand_col0, hipStream_t st);
-hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, hipStream_t st);
+hipError_t launch_fold_queries(const float *R, int d, int scorer, const PrefixDev &p, const float *ent_rows, float *Q, int ldq,
+                               int Bpad, hipStream_t st);
+hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, const double *loss_partials,
+                              int n_partials, double *loss_out, hipStream_t st);
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
                                   const float *slab, int nsplit, int Bpad, int ldq, const float *ent_rows, float *dE,
                                   float *dR, const double *loss_partials, int n_partials, double *loss_out,
@@ -90,6 +94,8 @@ hipError_t launch_bn_apply(const float *X, int64_t ldx, int n, int d, const floa
 hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
                                 int pool, const float *X, int64_t ldx, const float *DY, int64_t lddy, float *saved,
                                 const float *weight, float *d_weight, float *d_bias, float *dW, float *partial, hipStream_t st);
+hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
+                            int cand_first, int exclusive, int grads_zero, float *dE, hipStream_t st);
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,

@@ -34,6 +34,15 @@ __device__ __forceinline__ RowSrc row_source(const PrefixDev &p, int b)
     return r;
 }
 
+// ComplEx query fold, written with explicit roundings (no fma contraction) so that every kernel that folds the same
+// masked rows produces the same bits:  sp [s1 r1 - s2 r2 , s2 r1 + s1 r2]   po [o1 r1 + o2 r2 , o2 r1 - o1 r2]
+__device__ __forceinline__ void fold_complex(bool sp, float e1, float e2, float r1, float r2, float &q1, float &q2)
+{
+    const float a = __fmul_rn(e1, r1), b = __fmul_rn(e2, r2), c = __fmul_rn(e2, r1), dd = __fmul_rn(e1, r2);
+    q1 = sp ? __fsub_rn(a, b) : __fadd_rn(a, b);
+    q2 = sp ? __fadd_rn(c, dd) : __fsub_rn(c, dd);
+}
+
 __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                              int d, int scorer, const PrefixDev p,
                                                              float *__restrict__ Q, int ldq, int Bpad,
@@ -49,14 +58,14 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
         return;
     }
     const int b = blockIdx.x, B = p.n_po + p.n_sp;
-    float *q = Q + (size_t)b * ldq;
+    float *q = Q ? Q + (size_t)b * ldq : nullptr;         // Q == nullptr: only the masked entity rows are wanted
     float *er = ent_rows ? ent_rows + (size_t)b * ldq : nullptr;
     RowSrc rs;
     rs.owned = false;
     if (b < B) rs = row_source(p, b);
     if (!rs.owned) {       // padding row, or a prefix whose entity lives on another rank: contributes zero
         for (int k = threadIdx.x; k < ldq; k += blockDim.x) {
-            q[k] = 0.f;
+            if (q) q[k] = 0.f;
             if (er) er[k] = 0.f;
         }
         return;
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
     if (scorer == SC_DISTMULT) {
         for (int k = threadIdx.x; k < d; k += blockDim.x) {
             const float ev = e[k] * drop_mult1(de, rs.pos, k, d);
-            q[k] = ev * (r[k] * drop_mult1(dr, rs.pos, k, d));
+            if (q) q[k] = __fmul_rn(ev, __fmul_rn(r[k], drop_mult1(dr, rs.pos, k, d)));
             if (er) er[k] = ev;
         }
     } else {
@@ -75,26 +84,69 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
         for (int k = threadIdx.x; k < h; k += blockDim.x) {
             const float e1 = e[k] * drop_mult1(de, rs.pos, k, d), e2 = e[h + k] * drop_mult1(de, rs.pos, h + k, d);
             const float r1 = r[k] * drop_mult1(dr, rs.pos, k, d), r2 = r[h + k] * drop_mult1(dr, rs.pos, h + k, d);
-            if (rs.sp) {           // [s1 r1 - s2 r2 , s2 r1 + s1 r2]
-                q[k] = e1 * r1 - e2 * r2;
-                q[h + k] = e2 * r1 + e1 * r2;
-            } else {               // [o1 r1 + o2 r2 , o2 r1 - o1 r2]
-                q[k] = e1 * r1 + e2 * r2;
-                q[h + k] = e2 * r1 - e1 * r2;
-            }
+            if (q) fold_complex(rs.sp, e1, e2, r1, r2, q[k], q[h + k]);
             if (er) { er[k] = e1; er[h + k] = e2; }
         }
     }
     for (int k = d + threadIdx.x; k < ldq; k += blockDim.x) {
-        q[k] = 0.f;
+        if (q) q[k] = 0.f;
         if (er) er[k] = 0.f;
+    }
+}
+
+// Q[b] = fold(masked entity row b, dropout(R[rel_b])) from ALREADY MASKED entity rows (sharded path: the rows arrive
+// through the all-reduce; the replicated relation table and the counter-based masks let every rank fold them itself,
+// so only B x d floats cross the links instead of 2 x B x d).  Same arithmetic as encode_queries_kernel: bit-identical.
+__global__ __launch_bounds__(128) void fold_queries_kernel(const float *__restrict__ R, int d, int scorer, const PrefixDev p,
+                                                           const float *__restrict__ ent_rows, float *__restrict__ Q, int ldq)
+{
+    const int b = blockIdx.x, B = p.n_po + p.n_sp;
+    float *q = Q + (size_t)b * ldq;
+    if (b >= B) {
+        for (int k = threadIdx.x; k < ldq; k += blockDim.x) q[k] = 0.f;
+        return;
+    }
+    const RowSrc rs = row_source(p, b);
+    const DropDev &dr = rs.sp ? p.drop_sp_rel : p.drop_po_rel;
+    const float *e = ent_rows + (size_t)b * ldq, *r = R + rs.rel * d;
+    if (scorer == SC_DISTMULT) {
+        for (int k = threadIdx.x; k < d; k += blockDim.x) q[k] = __fmul_rn(e[k], __fmul_rn(r[k], drop_mult1(dr, rs.pos, k, d)));
+    } else {
+        const int h = d >> 1;
+        for (int k = threadIdx.x; k < h; k += blockDim.x) {
+            const float e1 = e[k], e2 = e[h + k];
+            const float r1 = r[k] * drop_mult1(dr, rs.pos, k, d), r2 = r[h + k] * drop_mult1(dr, rs.pos, h + k, d);
+            fold_complex(rs.sp, e1, e2, r1, r2, q[k], q[h + k]);
+        }
+    }
+    for (int k = d + threadIdx.x; k < ldq; k += blockDim.x) q[k] = 0.f;
+}
+
+__device__ __forceinline__ void loss_reduce_block(const double *__restrict__ partials, int n, double *__restrict__ out)
+{
+    __shared__ double red[4];
+    const int nw = blockDim.x >> 6;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < nw; ++i) t += red[i];
+        out[0] = t;
     }
 }
 
 // dQ[b][k] = sum over candidate ranges of the dq_kernel slabs (sharded path: reduced before the all-reduce)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, int nsplit, int64_t n4,
-                                                          float *__restrict__ out)
+                                                          float *__restrict__ out, const double *__restrict__ loss_partials,
+                                                          int n_partials, double *__restrict__ loss_out)
 {
+    if (blockIdx.x == gridDim.x - 1) {                      // one extra workgroup: the deterministic loss reduction
+        if (loss_partials) loss_reduce_block(loss_partials, n_partials, loss_out);
+        return;
+    }
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -103,6 +155,33 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     reinterpret_cast<float4 *>(out)[i] = acc;
+}
+
+// dE[candidate n] (+)= sum over the batch splits of the fused tile kernel's partial candidate-gradient slabs
+// (one thread per 4 columns; rows of repeated candidate ids accumulate with atomics)
+__global__ __launch_bounds__(256) void dc_reduce_kernel(const float *__restrict__ slab, int nsplit, int rows_pad, int D16,
+                                                        int N, int d, const int32_t *__restrict__ cand_ids, int cand_first,
+                                                        int exclusive, int grads_zero, float *__restrict__ dE)
+{
+    const int q4 = D16 >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * q4) return;
+    const int n = (int)(i / q4), k = 4 * (int)(i % q4);
+    if (k >= d) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sidx = 0; sidx < nsplit; ++sidx) {
+        const float4 v = *reinterpret_cast<const float4 *>(slab + ((size_t)sidx * rows_pad + n) * D16 + k);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int64_t cid = cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n;
+    float *dst = dE + cid * d + k;
+    const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (k + e >= d) break;
+        if (!exclusive) atomicAdd(dst + e, v[e]);
+        else dst[e] = grads_zero ? v[e] : dst[e] + v[e];
+    }
 }
 
 __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__restrict__ E, const float *__restrict__ R,
@@ -159,22 +238,6 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
         }
         atomicAdd(gr + k, dr1 * mr1);
         atomicAdd(gr + h + k, dr2 * mr2);
-    }
-}
-
-__device__ __forceinline__ void loss_reduce_block(const double *__restrict__ partials, int n, double *__restrict__ out)
-{
-    __shared__ double red[4];
-    const int nw = blockDim.x >> 6;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partials[i];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < nw; ++i) t += red[i];
-        out[0] = t;
     }
 }
 
@@ -565,11 +628,31 @@ hipError_t launch_encode_queries(const float *E, const float *R, int d, int scor
     return hipGetLastError();
 }
 
-hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, hipStream_t st)
+hipError_t launch_fold_queries(const float *R, int d, int scorer, const PrefixDev &p, const float *ent_rows, float *Q, int ldq,
+                               int Bpad, hipStream_t st)
+{
+    if (Bpad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fold_queries_kernel, dim3(Bpad), dim3(128), 0, st, R, d, scorer, p, ent_rows, Q, ldq);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, const double *loss_partials,
+                              int n_partials, double *loss_out, hipStream_t st)
 {
     const int64_t n4 = n / 4;
     if (n4 <= 0) return hipSuccess;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, nsplit, n4, out);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256) + 1), dim3(256), 0, st, slab, nsplit, n4, out,
+                       loss_partials, n_partials, loss_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
+                            int cand_first, int exclusive, int grads_zero, float *dE, hipStream_t st)
+{
+    const int64_t total = (int64_t)N * (D16 / 4);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dc_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, nsplit, rows_pad, D16, N,
+                       d, cand_ids, cand_first, exclusive, grads_zero, dE);
     return hipGetLastError();
 }
 

@@ -374,6 +374,10 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
             const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
             float *drow = a.dE + cid * d;
             const bool exclusive = gridDim.y == 1 && a.cand_exclusive;    // one workgroup per entity row: plain stores
+            // batch split over blockIdx.y: every workgroup stores ITS partial rows into a slab (plain 16-byte stores);
+            // dc_reduce_kernel sums the slabs into dE.  (Float atomics from gridDim.y workgroups per row cost more than
+            // the whole tile sweep: 3.4 M atomics = ~120 us at the 8-rank FB shape.)
+            float *srow = gridDim.y > 1 ? a.dC_slab + ((size_t)blockIdx.y * gridDim.x * NT32 + n) * (16 * KB) : nullptr;
 #pragma unroll
             for (int it = 0; it < NOIT; ++it) {
                 const int o = q8 + 8 * it, k = 8 * o;
@@ -389,6 +393,11 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
                         v[0][e] *= (bits >> e & 1u) ? a.drop_c.scale : 0.f;
                         v[1][e] *= (bits >> (4 + e) & 1u) ? a.drop_c.scale : 0.f;
                     }
+                }
+                if (srow) {                                   // 16*KB columns per slab row: k + 8 <= 16*KB always
+                    *reinterpret_cast<v4f *>(srow + k) = v[0];
+                    *reinterpret_cast<v4f *>(srow + k + 4) = v[1];
+                    continue;
                 }
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {

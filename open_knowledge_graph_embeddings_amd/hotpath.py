@@ -232,6 +232,31 @@ class HotPath:
         del keep
         return out
 
+    def encode_entity_rows(self, E_local, R, scorer, batch: PrefixBatch, shard: Shard, out=None):
+        """-> [rows][ld] masked prefix entity rows of the prefixes whose entity lives here, zeros elsewhere (the
+        caller all-reduces the buffer, then every rank calls fold_queries)."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E_local, R, scorer)
+        rows, ld = self.query_shape(batch.B, t.d)
+        if out is None:
+            out = torch.empty((rows, ld), dtype=torch.float32, device=self.device)
+        sh = shard.c()
+        N.check(self.lib.okge_encode_queries(ctypes.byref(t), ctypes.byref(sh), ctypes.byref(pb), None, ld,
+                                             out.data_ptr(), self._stream()), "okge_encode_queries")
+        del keep
+        return out
+
+    def fold_queries(self, E_local, R, scorer, batch: PrefixBatch, ent_rows, out=None):
+        """query block from exchanged masked entity rows and the replicated relation table"""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E_local, R, scorer)
+        if out is None:
+            out = torch.empty_like(ent_rows)
+        N.check(self.lib.okge_fold_queries(ctypes.byref(t), ctypes.byref(pb), ent_rows.data_ptr(), ent_rows.stride(0),
+                                           out.data_ptr(), self._stream()), "okge_fold_queries")
+        del keep
+        return out
+
     def train_tiles(self, E_local, R, scorer, Q, batch: PrefixBatch, shard: Shard, dE, dQ, n_cand_global, loss="bce",
                     label_smoothing=0.0, normalizer=None, loss_out=None, grads_zero=False, row_lse=None):
         """Local candidates only: batch.cand_first / n_cand are LOCAL row indices, batch.pos_col GLOBAL columns.

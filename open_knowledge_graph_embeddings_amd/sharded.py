@@ -6,8 +6,10 @@ Every rank processes the SAME batch of prefixes against ITS OWN slice of the can
 (tensor-parallel over the candidate axis); scores are independent per candidate and the BCE
 loss is separable, so one step needs exactly two small exchanges:
 
-    all-reduce(sum)  [2, B, d]  folded queries + masked prefix entity rows   (each row is non-zero on its owner)
-    all-reduce(sum)  [B, d]     partial query gradients dQ                    (+ the scalar loss, off the critical path)
+    all-reduce(sum)  [B, d]     masked prefix entity rows (each row is non-zero on its owner); every rank then folds
+                                them with its replicated relation rows into the query block itself
+    all-reduce(sum)  [B, d]     partial query gradients dQ
+(the scalar loss stays a per-rank partial until `reduce_loss()` is called: the reference looks at it every 100 steps)
 
 The KL loss (log_softmax over ALL candidates, trainer.py:99-101) adds one: all-gather of the [B] per-shard row
 log-sum-exp.  Evaluation (`ShardedEvaluator`) exchanges the true-answer scores (all-reduce max) and the integer
@@ -78,9 +80,10 @@ class ShardedTrainStep:
         self.steps += 1
         self._set_dropout(batch)
         eng = self.engine
-        # 1. queries of the prefixes whose entity lives here; sum over ranks = all queries
-        qe = eng.encode_queries(self.E, self.R, self.scorer, batch, self.shard)
-        dist.all_reduce(qe, group=self.group)
+        # 1. masked entity rows of the prefixes whose entity lives here; sum over ranks = all rows; fold locally
+        er = eng.encode_entity_rows(self.E, self.R, self.scorer, batch, self.shard)
+        dist.all_reduce(er, group=self.group)
+        qe = (eng.fold_queries(self.E, self.R, self.scorer, batch, er), er)
         # 2. local candidates: loss partial, local entity gradients, partial query gradients
         local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
                               pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=self.cand_first_local,
@@ -97,14 +100,20 @@ class ShardedTrainStep:
                         normalizer=float(batch.B) * float(self.n_cand_global), loss_out=self.loss_out, grads_zero=True,
                         row_lse=row_lse)
         dist.all_reduce(dq, group=self.group)
-        loss_work = dist.all_reduce(self.loss_out, group=self.group, async_op=True)
         # 3. chain rule: entity rows by their owner, relation rows everywhere (identical)
         eng.prefix_backward(self.E, self.R, self.scorer, batch, self.shard, dq, qe[1], self.dE, self.dR)
         # 4. dense Adagrad on the local entity rows and on the replicated relation table
         eng.adagrad2(self.E, self.dE, self.sumE, self.R, self.dR, self.sumR, self.lr, self.weight_decay, self.eps,
                      zero_grad=True)
-        loss_work.wait()
         return self.loss_out
+
+    def reduce_loss(self):
+        """The step's summed loss over ALL candidates (the value `step` returns covers this rank's candidates only).
+        One small all-reduce, paid only when somebody looks at the loss: the reference prints it every
+        `print_freq` = 100 steps (trainer.py:296-330), so it is kept off the per-step path."""
+        total = self.loss_out.clone()
+        dist.all_reduce(total, group=self.group)
+        return total
 
 
 class ShardedEvaluator:
@@ -128,8 +137,9 @@ class ShardedEvaluator:
 
     def local_scores(self, batch: H.PrefixBatch):
         eng = self.engine
-        qe = eng.encode_queries(self.E, self.R, self.scorer, batch, self.shard)
-        dist.all_reduce(qe, group=self.group)
+        er = eng.encode_entity_rows(self.E, self.R, self.scorer, batch, self.shard)
+        dist.all_reduce(er, group=self.group)
+        qe = (eng.fold_queries(self.E, self.R, self.scorer, batch, er), er)
         local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
                               cand_first=self.cand_first_local, n_cand=self.n_cand_local)
         return eng.score_queries(self.E, self.R, self.scorer, qe[0], batch.B, local, self.shard)

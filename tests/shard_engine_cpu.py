@@ -58,6 +58,36 @@ class OracleShardEngine:
                 buf[1, b, :d] = e
         return torch.from_numpy(buf)
 
+    def encode_entity_rows(self, E_local, R, scorer, batch, shard, out=None):
+        return self.encode_queries(E_local, R, scorer, batch, shard)[1]
+
+    def fold_queries(self, E_local, R, scorer, batch, ent_rows, out=None):
+        kind = ko.KIND_NAMES[scorer]
+        d = E_local.shape[1]
+        er = _np(ent_rows)
+        q = np.zeros_like(er)
+        whole = H.Shard(0, 1 << 30, 0)                  # relation rows and masks only: ownership is irrelevant here
+        for b, (direction, _owned, _e, r, *_rest) in enumerate(self._rows_any(R, scorer, batch, d)):
+            q[b, :d] = ko.prefix_query(kind, direction, er[b:b + 1, :d], r[None])[0]
+        del whole
+        return torch.from_numpy(q)
+
+    def _rows_any(self, R, scorer, batch, d):
+        """per batch row: (dir, True, None, masked r row) -- relation side only"""
+        Rn = _np(R)
+        parts = []
+        if batch.n_po:
+            parts.append((ko.DIR_PO, _np(batch.po_rel), batch.drop_po_rel))
+        if batch.n_sp:
+            parts.append((ko.DIR_SP, _np(batch.sp_rel), batch.drop_sp_rel))
+        out = []
+        for direction, rel_ids, dr in parts:
+            kr = _keep(dr, len(rel_ids), d)
+            for i in range(len(rel_ids)):
+                mr = np.ones(d, np.float32) if kr is None else kr[i].astype(np.float32) / np.float32(1 - dr.p)
+                out.append((direction, True, None, Rn[int(rel_ids[i])] * mr))
+        return out
+
     def _local_scores(self, E_local, Q, B, batch, shard):
         E = _np(E_local)
         d = E.shape[1]

@@ -120,7 +120,8 @@ def _worker(rank, world, port, outdir, nsteps, loss):
                           input_dropout=P_DROP, seed=SEED, engine=OracleShardEngine(), loss=loss)
     losses = []
     for step in range(1, nsteps + 1):
-        losses.append(float(st.step(to_batch(problem(step), "cpu"))[0]))
+        st.step(to_batch(problem(step), "cpu"))
+        losses.append(float(st.reduce_loss()[0]))
     # checkpoint interop: shards gathered into the reference's state-dict layout, then scattered back
     from open_knowledge_graph_embeddings_amd.checkpoint import load_reference_checkpoint, save_checkpoint
     ck = save_checkpoint(os.path.join(outdir, "ckpt.pt"), st, epoch=1)
@@ -263,6 +264,9 @@ def test_three_phase_abi_emulated_shards(world, loss, okge_lib):
         shards.append((H.Shard(lo, hi, c_lo - 2), c_lo - lo, hi - c_lo))
         Es.append(torch.from_numpy(E[lo:hi].copy()).cuda())
     qe = sum(hp.encode_queries(Es[r], Rt, SCORER, batch, shards[r][0]) for r in range(world))     # "all-reduce"
+    # the production exchange: only the masked entity rows travel, every rank folds the queries itself -- bit-identical
+    er = sum(hp.encode_entity_rows(Es[r], Rt, SCORER, batch, shards[r][0]) for r in range(world))
+    assert torch.equal(er, qe[1]) and torch.equal(hp.fold_queries(Es[0], Rt, SCORER, batch, er), qe[0])
     dEs, dqs, losses = [], [], []
 
     def local_batch(r):
