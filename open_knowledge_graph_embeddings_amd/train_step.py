@@ -79,7 +79,7 @@ class GraphedTrainStep:
 
     PAD_COL = 2 ** 31 - 1
 
-    def __init__(self, inner, example: H.PrefixBatch, pos_capacity, normalizer=None):
+    def __init__(self, inner, example: H.PrefixBatch, pos_capacity, normalizer=None, counter=None):
         self.inner = inner
         dev = example.pos_row.device
         self.device = dev
@@ -91,7 +91,7 @@ class GraphedTrainStep:
             pos_row=i32(self.pos_capacity), pos_col=i32(self.pos_capacity),
             cand_ids=None if example.cand_ids is None else i32(example.cand_ids.numel()),
             cand_first=example.cand_first, n_cand=example.n_cand, cand_unique=example.cand_unique)
-        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev) if counter is None else counter
         inner.step_dev = self.counter
         self.normalizer = normalizer
         self._load(example)
@@ -106,7 +106,8 @@ class GraphedTrainStep:
         for t, s0 in zip(state, saved):                     # the warm-up steps must not count as training
             t.copy_(s0)
         inner.steps = steps0
-        self.counter.fill_(steps0)
+        if counter is None:
+            self.counter.fill_(steps0)
         del saved
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -132,5 +133,10 @@ class GraphedTrainStep:
     def step(self, batch: H.PrefixBatch):
         """Copies the batch into the captured buffers and replays; returns the device loss (double[1])."""
         self._load(batch)
+        self.graph.replay()
+        return self.loss
+
+    def replay(self):
+        """Replays on whatever the captured buffers hold (a producer may fill `self.static` directly)."""
         self.graph.replay()
         return self.loss
