@@ -266,3 +266,45 @@ def test_files_to_batches_end_to_end(okge_lib):
         np.testing.assert_array_equal(cb.filt_col.numpy(), np.asarray([c for f in ref["filters"] for c in f], np.int32))
         n += cb.batch.B
     assert n == 91
+
+
+@pytest.mark.gpu
+def test_toy_kg_end_to_end_training_improves_mrr(okge_lib):
+    """files -> loader -> producer -> fused train steps -> score + filtered ranks: the model must learn the toy KG
+    (training split as evaluation data: filtered MRR goes from chance to near-perfect memorisation)."""
+    from conftest import GOLDEN
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.dataset import OneToNBatchProducer, dataset_meta, load_dataset_tensors
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+    toy = os.path.join(GOLDEN, "toy_kg")
+    # evaluate on the training triples: use train.txt as the "valid" split too, so its rows carry filter slices
+    out, all_splits, _ = load_dataset_tensors(toy, "train.txt", "train.txt", "test.txt")
+    meta = dataset_meta(toy)
+    d = 32
+    g = torch.Generator().manual_seed(0)
+    E = (torch.randn((meta.entities_size, d), generator=g) * 0.1).cuda()
+    R = (torch.randn((meta.relations_size, d), generator=g) * 0.1).cuda()
+    train = OneToNBatchProducer(*out["train"], all_splits, meta.entities_size, batch_size=32, is_training_data=True,
+                                shuffle=True, seed=1, device="cuda:0")
+    valid = OneToNBatchProducer(*out["valid"], all_splits, meta.entities_size, batch_size=64, is_training_data=False,
+                                drop_last=False, device="cuda:0")
+    step = FusedTrainStep(E, R, "complex", lr=0.3, input_dropout=0.1, seed=3)
+    hp = step.engine
+
+    def mrr():
+        rr, n = 0.0, 0
+        for cb in valid:
+            x = hp.score(E, R, "complex", cb.batch)
+            ranks = hp.filtered_ranks(x, cb.filt_ptr, cb.filt_col, cb.row_ptr, cb.grp_ptr, cb.ids)
+            rr += float((1.0 / (ranks.double() + 1.0)).sum())
+            n += ranks.numel()
+        return rr / n
+
+    before = mrr()
+    losses = []
+    for _ in range(60):
+        for cb in train:
+            losses.append(float(step.step(cb.batch, normalizer=cb.normalizer_loss)[0]))      # loss_out is reused: read now
+    after = mrr()
+    first, last = losses[0], losses[-1]
+    assert before < 0.25 and after > 0.8 and last < 0.5 * first, (before, after, first, last)
