@@ -27,6 +27,11 @@ Vectors:
                   AddLossModule forward + backward -> loss, outputs, token-table / batch-norm gradients, running
                   stats; eval-mode precompute_embeddings_from_tokens.  The reference class lacks the attribute
                   `entity_projection` it reads (model.py:789); the harness sets it to None on the instance.
+  g10_fb15k237    the FIRST 512-prefix evaluation batch of FB15k-237 valid.txt as the reference's dataset + collate
+                  produce it, scored / trained / ranked by the reference at the full BASELINE size (|E|=14543, d=200):
+                  ids, label / filter coordinates and answer groups, a score slice, per-row score sums, loss,
+                  gradient checksums, ranks.  The tables are regenerated from the seed by the test
+                  (torch.manual_seed + the same constructor order), guarded by checksums.
   g5_ranks_*      OneToNMentionRelationDataset.compute_metrics (known answer + ties + mention groups)
   g8_checkpoint   the checkpoint dict Trainer.save writes (state_dict + OptimRegime.state_dict()) after two steps,
                   stored with torch.save (tensors / containers only), plus the third step's batch and result
@@ -578,6 +583,83 @@ def g9():
 
 
 # ----------------------------------------------------------------------------------------------
+# G10: full-size FB15k-237 batch through the reference
+# ----------------------------------------------------------------------------------------------
+def g10():
+    import shutil
+    import tempfile
+    from openkge.dataset import OneToNMentionRelationDataset_collate_func as collate
+    fb = "/root/reference/data/fb15k237/mapped_to_ids"
+    scratch = tempfile.mkdtemp(prefix="okge_g10_")
+    try:
+        for f in os.listdir(fb):
+            shutil.copy(os.path.join(fb, f), scratch)
+        files = {"train": "test.txt", "valid": "valid.txt", "test": "test.txt"}     # train split absent upstream
+        ds = {}
+        for split in ("train", "valid"):
+            ds[split] = OneToNMentionRelationDataset(dataset_dir=scratch, input_file=files[split],
+                                                     is_training_data=(split == "train"), batch_size=512, copy_data_to_dev_shm=False)
+        ds["valid"].merge_all_splits_triples(dataset_dir=scratch, train_input_file=files["train"],
+                                             valid_input_file=files["valid"], test_input_file=files["test"])
+        ds["valid"].create_data_tensors(dataset_dir=scratch, train_input_file=files["train"],
+                                        valid_input_file=files["valid"], test_input_file=files["test"])
+        v = ds["valid"]
+        n_ent, n_rel = v.entity_vocab_size, v.relations_size
+        # 256 po rows (slot 0) and 256 sp rows (slot 2), taken from the start of each block of the prefix table
+        pref = v.seen_prefixes_tensor
+        slot = pref[:, 6]
+        rows = torch.cat([torch.nonzero(slot == 0).view(-1)[:256], torch.nonzero(slot == 2).view(-1)[:256]])
+        out = collate(use_batch_shared_entities=False, sp_po__batch=[pref[i] for i in rows.tolist()],
+                      entity_vocab_size=n_ent, entity_vocab_offset=2, is_training_data=False,
+                      this_split_entities_list=v.seen_entities_tensor, all_splits_entities_tensor=v.all_splits_entities_tensor,
+                      min_size_batch_labels=0)
+        inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = out
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    seed, d = 2024, 200
+    m = make_model("LookupComplexRelationModel", n_ent, n_rel, d, seed=seed, init_std=0.1)
+    E, R = npy(m.entity_embedding.weight), npy(m.relation_embedding.weight)
+    m.eval()
+    with torch.no_grad():
+        po = m.po_prefix_score(inputs[0][0], inputs[0][1])
+        sp = m.sp_prefix_score(inputs[1][0], inputs[1][1])
+        scores = torch.cat([po, sp], 0)
+    metrics = OneToNMentionRelationDataset.compute_metrics(filter_mask=filt, label_ids=label_ids, predictions=scores.clone())
+    # per-group ranks with the reference's own rule on its own scores (dataset.py:436-446)
+    ranks = []
+    masked_all = scores.clone()
+    for b in range(scores.shape[0]):
+        masked = scores[b].clone()
+        masked[filt[b]] = -1e8
+        for gidx in label_ids[b]:
+            true = scores[b][gidx.long()].max()
+            ranks.append(int((masked > true).sum()) + int((masked == true).sum()) // 2)
+    del masked_all
+    m.train()
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+    mod.train()
+    loss, _, outputs = mod(inputs=list(inputs), labels=labels.clone(), use_batch_shared_entities=False,
+                           batch_shared_entities=cand, epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+    (loss.sum() / float(norm_loss)).backward()
+    dE, dR = npy(m.entity_embedding.weight.grad), npy(m.relation_embedding.weight.grad)
+    rp, gp, ids = pack_groups(label_ids)
+    fnz = npy(filt.nonzero()).astype(np.int32)
+    lnz = npy(labels.nonzero()).astype(np.int32)
+    save("g10_fb15k237_batch",
+         seed=np.int64(seed), n_ent=np.int64(n_ent), n_rel=np.int64(n_rel), d=np.int64(d),
+         table_check=np.asarray([E.sum(dtype=np.float64), np.abs(E).sum(dtype=np.float64), R.sum(dtype=np.float64),
+                                 float(E[5, 7]), float(E[-1, -1]), float(R[3, 4])], np.float64),
+         po_rel=npy(inputs[0][0]), po_obj=npy(inputs[0][1]), sp_subj=npy(inputs[1][0]), sp_rel=npy(inputs[1][1]),
+         labels=lnz, filter=fnz, row_ptr=rp, grp_ptr=gp, ids=ids, prefix_rows=npy(rows).astype(np.int64),
+         score_slice=npy(scores[192:320, 1000:1128]), score_row_sum=npy(scores.double().sum(1)),
+         score_row_absmax=npy(scores.abs().max(1).values), ranks=np.asarray(ranks, np.int64),
+         mrr=np.float64(metrics["mrr"].avg) if "mrr" in metrics else np.float64(-1),
+         loss=np.float64(loss.item()), normalizer=np.float64(norm_loss), n_labels=np.float64(norm_metric),
+         dE_row_sum=dE.astype(np.float64).sum(1), dE_abs_sum=np.float64(np.abs(dE).sum(dtype=np.float64)),
+         dE_slice=dE[2:66, :16].copy(), dR=dR)
+
+
+# ----------------------------------------------------------------------------------------------
 # G8: checkpoint interop (Trainer.save layout, trainer.py:608-618)
 # ----------------------------------------------------------------------------------------------
 def g8():
@@ -623,7 +705,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -1,0 +1,104 @@
+"""Full BASELINE-size parity on a real FB15k-237 batch (tests/golden/g10_fb15k237_batch.npz): the first 256 po + 256 sp
+prefixes of valid.txt as the reference's dataset class and collate function produce them, scored, ranked and
+back-propagated by the reference's LookupComplexRelationModel (d=200, |E|=14543).  The embedding tables are not stored:
+they are regenerated from the seed (same constructor order as the reference => identical torch CPU RNG stream), which
+the stored checksums verify before anything else is compared.
+
+CPU: the oracle.  GPU: the HIP path through the C ABI (scores within the north-star 1e-4, in fact ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import kge_oracle as ko
+
+
+def tables(z):
+    from open_knowledge_graph_embeddings_amd.dataset import EntityRelationDatasetMeta
+    from open_knowledge_graph_embeddings_amd.model import Models
+    torch.manual_seed(int(z["seed"]))
+    m = Models.LookupComplexRelationModel(entity_slot_size=int(z["d"]), input_dropout=0.0, init_std=0.1, sparse=False,
+                                          train_data=EntityRelationDatasetMeta(entities_size=int(z["n_ent"]),
+                                                                              relations_size=int(z["n_rel"])))
+    E, R = m.entity_embedding.weight.detach().numpy().copy(), m.relation_embedding.weight.detach().numpy().copy()
+    chk = [E.sum(dtype=np.float64), np.abs(E).sum(dtype=np.float64), R.sum(dtype=np.float64), float(E[5, 7]),
+           float(E[-1, -1]), float(R[3, 4])]
+    np.testing.assert_array_equal(np.asarray(chk), z["table_check"])          # same tables as the reference built
+    return m, E, R
+
+
+def check_scores(x, z):
+    np.testing.assert_allclose(x[192:320, 1000:1128], z["score_slice"], rtol=0, atol=1e-4)
+    assert np.abs(x[192:320, 1000:1128] - z["score_slice"]).max() < 5e-6
+    np.testing.assert_allclose(x.astype(np.float64).sum(1), z["score_row_sum"], rtol=0, atol=2e-3)   # 14541 terms per row
+    np.testing.assert_allclose(np.abs(x).max(1), z["score_row_absmax"], rtol=0, atol=1e-5)
+
+
+def check_ranks(ranks, z):
+    """the rank RULE is exact; against the reference's own float scores a near-tie may flip a neighbour"""
+    ref = z["ranks"]
+    assert ranks.shape == ref.shape
+    assert (ranks != ref).mean() < 0.02 and np.abs(ranks - ref).max() <= 2
+    mrr = float((1.0 / (ranks + 1.0)).mean())
+    assert abs(mrr - float((1.0 / (ref + 1.0)).mean())) < 1e-5
+
+
+def dense(coords, shape, dtype):
+    y = np.zeros(shape, dtype)
+    y[coords[:, 0], coords[:, 1]] = 1
+    return y
+
+
+def test_oracle_on_fb15k237_batch():
+    z = golden("g10_fb15k237_batch")
+    _, E, R = tables(z)
+    N = E.shape[0] - 2
+    po, sp = (z["po_rel"], z["po_obj"]), (z["sp_subj"], z["sp_rel"])
+    y = dense(z["labels"], (512, N), np.float32)
+    out = ko.step_forward_backward(ko.COMPLEX, E, R, po, sp, np.arange(2, E.shape[0]), y, normalizer=float(z["normalizer"]))
+    check_scores(out["outputs"], z)
+    assert abs(out["loss"] - float(z["loss"])) <= 2e-6 * float(z["loss"]) and float(z["n_labels"]) == len(z["labels"])
+    np.testing.assert_allclose(out["dE"].astype(np.float64).sum(1), z["dE_row_sum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["dE"][2:66, :16], z["dE_slice"], rtol=0, atol=2e-5 * np.abs(z["dE_slice"]).max())
+    np.testing.assert_allclose(out["dR"], z["dR"], rtol=0, atol=2e-5 * np.abs(z["dR"]).max())
+    ranks = ko.filtered_ranks(out["outputs"], dense(z["filter"], (512, N), bool), z["row_ptr"], z["grp_ptr"], z["ids"])
+    check_ranks(ranks, z)
+
+
+@pytest.mark.gpu
+def test_hip_on_fb15k237_batch(okge_lib):
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    z = golden("g10_fb15k237_batch")
+    m, E, R = tables(z)
+    dev = lambda a, dt=None: (torch.from_numpy(np.ascontiguousarray(a)) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dt)).cuda()  # noqa: E731
+    m = m.cuda().eval()
+    po_rel, po_obj, sp_subj, sp_rel = (dev(z[k]) for k in ("po_rel", "po_obj", "sp_subj", "sp_rel"))
+    # 1. the model API, as the reference's evaluation calls it
+    x = torch.cat([m.po_prefix_score(po_rel, po_obj), m.sp_prefix_score(sp_subj, sp_rel)], 0)
+    check_scores(x.cpu().numpy(), z)
+    # 2. filtered ranks from CSR answer groups / filter
+    hp = H.HotPath("cuda:0")
+    f = z["filter"]
+    fp = np.concatenate([[0], np.cumsum(np.bincount(f[:, 0], minlength=512))]).astype(np.int64)
+    ranks = hp.filtered_ranks(x.contiguous(), dev(fp), dev(f[:, 1].astype(np.int32)), dev(z["row_ptr"]), dev(z["grp_ptr"]),
+                              dev(z["ids"])).cpu().numpy()
+    check_ranks(ranks, z)
+    # the rule itself is bit-exact on identical scores
+    N = E.shape[0] - 2
+    np.testing.assert_array_equal(ranks, ko.filtered_ranks(x.cpu().numpy(), dense(f, (512, N), bool), z["row_ptr"],
+                                                           z["grp_ptr"], z["ids"]))
+    # 3. the fused training step's forward + backward
+    lab = z["labels"]
+    order = np.lexsort((lab[:, 0], lab[:, 1]))                     # by column, then row
+    batch = H.PrefixBatch(po_rel=po_rel.view(-1), po_obj=po_obj.view(-1), sp_subj=sp_subj.view(-1), sp_rel=sp_rel.view(-1),
+                          pos_row=dev(lab[order, 0].astype(np.int32)), pos_col=dev(lab[order, 1].astype(np.int32)),
+                          cand_first=2, n_cand=N)
+    Et, Rt = dev(E), dev(R)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = hp.forward_backward(Et, Rt, "complex", batch, dE, dR, normalizer=float(z["normalizer"]), grads_zero=True)
+    assert abs(float(loss[0]) - float(z["loss"])) <= 3e-6 * float(z["loss"])
+    dEn, dRn = dE.cpu().numpy(), dR.cpu().numpy()
+    np.testing.assert_allclose(dEn.astype(np.float64).sum(1), z["dE_row_sum"], rtol=0, atol=2e-9)
+    np.testing.assert_allclose(dEn[2:66, :16], z["dE_slice"], rtol=0, atol=3e-5 * np.abs(z["dE_slice"]).max())
+    np.testing.assert_allclose(dRn, z["dR"], rtol=0, atol=3e-5 * np.abs(z["dR"]).max())
+    assert abs(np.abs(dEn).sum(dtype=np.float64) - float(z["dE_abs_sum"])) <= 1e-5 * float(z["dE_abs_sum"])
