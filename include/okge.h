@@ -254,7 +254,10 @@ int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream
  * gradient buffer is cleared in the same sweep (replaces optimizer.zero_grad(), trainer.py:229-244). */
 int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr, float weight_decay,
                       float eps, int32_t zero_grad, void *stream);
-/* The same update on two parameter tensors (entity and relation table) in ONE launch. */
+/* The same update on two parameter tensors (entity and relation table) in ONE launch.
+ * zero_grad: 0 = keep both gradient buffers, 1 = clear both, 2 = clear only g1 -- for the 1-vs-all step, whose next
+ * okge_train_forward_backward(OKGE_TRAIN_GRADS_ZERO) overwrites every candidate row of dE anyway (rows below the first
+ * candidate are never written and stay zero), so clearing 4*|E|*d bytes per step would be wasted traffic. */
 int okge_adagrad_step2(float *p0, float *g0, float *sum0, int64_t n0, float *p1, float *g1, float *sum1,
                        int64_t n1, float lr, float weight_decay, float eps, int32_t zero_grad, void *stream);
 

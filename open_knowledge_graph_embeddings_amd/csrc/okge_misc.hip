@@ -465,8 +465,8 @@ __global__ __launch_bounds__(256) void adagrad2_kernel(const AdagradSeg a, const
                                                        float eps, int zero_grad)
 {
     const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
-    adagrad_sweep(a, lr, wd, eps, zero_grad, first, stride);
-    adagrad_sweep(b, lr, wd, eps, zero_grad, first, stride);
+    adagrad_sweep(a, lr, wd, eps, zero_grad == 1, first, stride);      // zero_grad: 0 none, 1 both, 2 second tensor only
+    adagrad_sweep(b, lr, wd, eps, zero_grad != 0, first, stride);
 }
 
 constexpr int RANK_GROUPS = 8;

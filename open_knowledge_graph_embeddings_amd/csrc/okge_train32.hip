@@ -410,7 +410,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
                     } else if (exclusive) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (kk + e < d) drow[kk + e] += v[hh][e];
+                            if (kk + e < d) drow[kk + e] = a.grads_zero ? v[hh][e] : drow[kk + e] + v[hh][e];
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)

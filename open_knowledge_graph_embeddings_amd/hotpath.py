@@ -355,10 +355,10 @@ class HotPath:
                 "okge_adagrad_step")
 
     def adagrad2(self, p0, g0, s0, p1, g1, s1, lr, weight_decay=1e-10, eps=1e-8, zero_grad=True):
-        """Both tables in one launch."""
+        """Both tables in one launch.  zero_grad: False/0 none, True/1 both, 2 only g1 (see include/okge.h)."""
         N.check(self.lib.okge_adagrad_step2(p0.data_ptr(), g0.data_ptr(), s0.data_ptr(), p0.numel(), p1.data_ptr(),
                                             g1.data_ptr(), s1.data_ptr(), p1.numel(), float(lr), float(weight_decay),
-                                            float(eps), 1 if zero_grad else 0, self._stream()), "okge_adagrad_step2")
+                                            float(eps), int(zero_grad), self._stream()), "okge_adagrad_step2")
 
     def filtered_ranks(self, scores, filt_ptr, filt_col, row_ptr, grp_ptr, ids):
         """int64 ranks per answer group; all index arrays on the device (int64 ptr arrays, int32 ids)."""

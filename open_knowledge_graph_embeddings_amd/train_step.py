@@ -29,6 +29,7 @@ class FusedTrainStep:
         self.steps = 0
         self.step_dev = None              # device step counter, attached by GraphedTrainStep
         self._grads_zero = True           # fresh buffers; kept true by the zero_grad fused into Adagrad
+        self._dE_stale = False            # dE holds last step's values (they get overwritten, not accumulated)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=E.device)
 
     def state_tensors(self):
@@ -45,23 +46,34 @@ class FusedTrainStep:
         batch.drop_po_rel = H.DropoutSpec(pr, s, H.STREAM_PO_REL, t, step_dev=sd)
         batch.drop_sp_rel = H.DropoutSpec(pr, s, H.STREAM_SP_REL, t, step_dev=sd)
 
+    def _covers_all_rows(self, batch: H.PrefixBatch):
+        """1-vs-all: the candidate range is every row from cand_first on, so the step overwrites all of dE it uses"""
+        return batch.cand_ids is None and batch.cand_first + batch.n_cand == self.E.shape[0]
+
     def forward_backward(self, batch: H.PrefixBatch, normalizer=None):
         """trainer.py:206-234.  Returns the summed loss (device double[1], valid after stream sync)."""
         self._set_dropout(batch)
+        if self._dE_stale and not (self._grads_zero and self._covers_all_rows(batch)):
+            self.dE.zero_()               # a sampled candidate list leaves rows untouched: they must read as zero
+            self._dE_stale = False
+        self._last_full = self._covers_all_rows(batch)
         return self.engine.forward_backward(self.E, self.R, self.scorer, batch, self.dE, self.dR, loss=self.loss,
                                             label_smoothing=self.label_smoothing, normalizer=normalizer,
                                             loss_out=self.loss_out, grads_zero=self._grads_zero)
 
-    def optimizer_step(self):
-        """trainer.py:240-244: optimizer.step() then zero_grad() -- one sweep per table."""
+    def optimizer_step(self, lazy_zero=False):
+        """trainer.py:240-244: optimizer.step() then zero_grad() -- one sweep per table.  lazy_zero (used by step()
+        after a 1-vs-all batch): the entity gradient is not cleared here because the next 1-vs-all step overwrites
+        every row it uses; it is cleared on demand if a sampled candidate list comes next."""
         self.engine.adagrad2(self.E, self.dE, self.sumE, self.R, self.dR, self.sumR, self.lr, self.weight_decay,
-                             self.eps, zero_grad=True)
+                             self.eps, zero_grad=2 if lazy_zero else 1)
+        self._dE_stale = bool(lazy_zero)
 
     def step(self, batch: H.PrefixBatch, normalizer=None):
         self.steps += 1
         loss = self.forward_backward(batch, normalizer)
         self._grads_zero = False
-        self.optimizer_step()
+        self.optimizer_step(lazy_zero=self._last_full)
         self._grads_zero = True
         return loss
 

@@ -415,3 +415,23 @@ def test_graphed_step_equals_plain_step(hp):
     with pytest.raises(ValueError):
         graphed.step(make_batch(*[random_problem(9, n_ent, n_rel, d, n_po + 1, n_sp)[i] for i in (2, 3)], n_ent,
                                 labels=random_problem(9, n_ent, n_rel, d, n_po + 1, n_sp)[4]))
+
+
+def test_train_step_lazy_gradient_clear(hp):
+    """FusedTrainStep leaves dE uncleared after a 1-vs-all step (the next one overwrites it); a sampled candidate
+    list next must see zeros in the rows it does not touch.  1-vs-all, sampled, 1-vs-all against the oracle."""
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+    n_ent, n_rel, d = 600, 12, 64
+    probs = [random_problem(900, n_ent, n_rel, d, 20, 20), random_problem(901, n_ent, n_rel, d, 20, 20, n_cand=150),
+             random_problem(902, n_ent, n_rel, d, 20, 20)]
+    E, R = probs[0][0].copy(), probs[0][1].copy()
+    st = FusedTrainStep(dev(E.copy()), dev(R.copy()), "complex", lr=0.3)
+    sE, sR = np.zeros_like(E), np.zeros_like(R)
+    for _, _, z, cand, y in probs:
+        loss = float(st.step(make_batch(z, cand, n_ent, labels=y))[0])
+        ref = oracle_step("complex", E, R, z, cand, y)
+        assert abs(loss - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+        ko.adagrad_step(E, ref["dE"], sE, 0.3)
+        ko.adagrad_step(R, ref["dR"], sR, 0.3)
+    np.testing.assert_allclose(st.sumE.cpu().numpy(), sE, rtol=2e-4, atol=1e-12)     # accumulators see every gradient
+    assert np.isclose(st.E.cpu().numpy(), E, rtol=1e-3, atol=1e-4).mean() > 0.999
