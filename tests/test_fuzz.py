@@ -1,0 +1,90 @@
+"""Randomised shape sweep of the fused step against the oracle (GPU): slot sizes across every kernel width incl. odd
+ones, one-sided batches, tiny and ragged candidate lists with repeats, both losses, label smoothing, Philox dropout on
+every stream, forced batch splits, zeroed-gradient fast path.  Seeds are fixed: failures reproduce."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as ko
+from test_hip_parity import dev, make_batch, oracle_step
+
+pytestmark = pytest.mark.gpu
+
+
+def case(i):
+    rng = np.random.default_rng(7000 + i)
+    scorer = "complex" if rng.random() < 0.6 else "distmult"
+    d = int(rng.choice([2, 6, 16, 30, 64, 100, 130, 200, 208, 256, 300, 400, 512]))
+    if scorer == "distmult" and rng.random() < 0.5:
+        d = int(rng.choice([1, 3, 17, 63, 129, 257]))                     # odd slot sizes (scalar paths)
+    n_ent = int(rng.integers(40, 900))
+    n_rel = int(rng.integers(4, 30))
+    n_po, n_sp = int(rng.integers(0, 90)), int(rng.integers(0, 90))
+    if n_po + n_sp == 0:
+        n_po = 5
+    mode = rng.choice(["all", "subset", "repeats", "one"])
+    if mode == "all":
+        cand = np.arange(2, n_ent)
+    elif mode == "subset":
+        cand = rng.permutation(np.arange(2, n_ent))[: int(rng.integers(1, n_ent - 2))]
+    elif mode == "repeats":
+        cand = rng.integers(2, n_ent, int(rng.integers(2, 400)))
+    else:
+        cand = rng.integers(2, n_ent, 1)
+    loss = "kl" if rng.random() < 0.3 else "bce"
+    smoothing = float(rng.choice([0.0, 0.0, 0.1])) if loss == "bce" else 0.0
+    p = float(rng.choice([0.0, 0.0, 0.3, 0.5]))
+    p_rel = float(rng.choice([0.0, 0.2])) if p > 0 else 0.0
+    split = str(int(rng.choice([0, 0, 1, 2, 5])))
+    return dict(i=i, scorer=scorer, d=d, n_ent=n_ent, n_rel=n_rel, n_po=n_po, n_sp=n_sp, cand=cand.astype(np.int32), loss=loss,
+                smoothing=smoothing, p=p, p_rel=p_rel, split=split, grads_zero=bool(rng.random() < 0.5), rng=rng)
+
+
+@pytest.mark.parametrize("i", range(48))
+def test_random_shape(okge_lib, monkeypatch, i):
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    c = case(i)
+    rng, d, B, Nc = c["rng"], c["d"], c["n_po"] + c["n_sp"], len(c["cand"])
+    E = (rng.standard_normal((c["n_ent"], d)) * 0.4).astype(np.float32)
+    R = (rng.standard_normal((c["n_rel"], d)) * 0.4).astype(np.float32)
+    z = {}
+    if c["n_po"]:
+        z["po_rel"], z["po_obj"] = rng.integers(2, c["n_rel"], c["n_po"]).astype(np.int32), rng.integers(2, c["n_ent"], c["n_po"]).astype(np.int32)
+    if c["n_sp"]:
+        z["sp_subj"], z["sp_rel"] = rng.integers(2, c["n_ent"], c["n_sp"]).astype(np.int32), rng.integers(2, c["n_rel"], c["n_sp"]).astype(np.int32)
+    y = np.zeros((B, Nc), np.float32)
+    for b in range(B):
+        y[b, rng.choice(Nc, size=int(rng.integers(0, min(4, Nc) + 1)), replace=False)] = 1        # rows without labels too
+    seed, step = 0xABCDEF12345 + i, 3 + i
+    kw = {}
+    if c["p"] > 0:
+        kw = dict(p_ent=c["p"], p_rel=c["p_rel"],
+                  keep_cand=ko.dropout_keep_mask(seed, H.STREAM_CAND, step, Nc, d, c["p"]),
+                  keep_po_ent=ko.dropout_keep_mask(seed, H.STREAM_PO_ENT, step, c["n_po"], d, c["p"]) if c["n_po"] else None,
+                  keep_sp_ent=ko.dropout_keep_mask(seed, H.STREAM_SP_ENT, step, c["n_sp"], d, c["p"]) if c["n_sp"] else None)
+        if c["p_rel"] > 0:
+            kw.update(keep_po_rel=ko.dropout_keep_mask(seed, H.STREAM_PO_REL, step, c["n_po"], d, c["p_rel"]) if c["n_po"] else None,
+                      keep_sp_rel=ko.dropout_keep_mask(seed, H.STREAM_SP_REL, step, c["n_sp"], d, c["p_rel"]) if c["n_sp"] else None)
+    ref = oracle_step(c["scorer"], E, R, z, c["cand"], y, c["loss"], c["smoothing"], **kw)
+    batch = make_batch(z, c["cand"], c["n_ent"], labels=y)
+    if c["p"] > 0:
+        batch.drop_cand = H.DropoutSpec(c["p"], seed, H.STREAM_CAND, step)
+        batch.drop_po_ent = H.DropoutSpec(c["p"], seed, H.STREAM_PO_ENT, step)
+        batch.drop_sp_ent = H.DropoutSpec(c["p"], seed, H.STREAM_SP_ENT, step)
+        batch.drop_po_rel = H.DropoutSpec(c["p_rel"], seed, H.STREAM_PO_REL, step)
+        batch.drop_sp_rel = H.DropoutSpec(c["p_rel"], seed, H.STREAM_SP_REL, step)
+    if c["split"] != "0":
+        monkeypatch.setenv("OKGE_B_SPLIT", c["split"])
+    hp = H.HotPath("cuda:0")
+    Et, Rt = dev(E), dev(R)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    scores = torch.empty((B, (Nc + 3) // 4 * 4), device="cuda:0")[:, :Nc]
+    loss = hp.forward_backward(Et, Rt, c["scorer"], batch, dE, dR, loss=c["loss"], label_smoothing=c["smoothing"],
+                               scores=scores, grads_zero=c["grads_zero"])
+    torch.cuda.synchronize()
+    info = {k: v for k, v in c.items() if k not in ("rng", "cand")}
+    np.testing.assert_allclose(scores.cpu().numpy(), ref["outputs"], rtol=0, atol=1e-4, err_msg=str(info))
+    # + an absolute term: a single-candidate KL loss is exactly 0 in the oracle and ~1e-6 of exp/log rounding here
+    assert abs(loss.item() - ref["loss"]) <= 5e-5 * abs(ref["loss"]) + 1e-5, (info, loss.item(), ref["loss"])
+    for mine, r in ((dE, ref["dE"]), (dR, ref["dR"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=5e-5 * np.abs(r).max() + 1e-12, err_msg=str(info))
