@@ -487,16 +487,25 @@ __device__ __forceinline__ void rank_sweep(const float *__restrict__ row, int64_
     for (int j = 0; j < NG; ++j) { g[j] = 0; e[j] = 0; }
     const int n4 = ld_is_vec ? (N >> 2) : 0;
     const float4 *row4 = reinterpret_cast<const float4 *>(row);
-    for (int i = tid; i < n4; i += 512) {                       // 16-byte loads, two in flight per thread
-        const float4 xa = row4[i];
-        const bool has_b = i + 256 < n4;
-        const float4 xb = has_b ? row4[i + 256] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    // 16-byte loads, four in flight per thread: a row is 58 KB at the FB15k-237 size and the sweep is a chain of memory
+    // round trips, not compares
+    for (int i = tid; i < n4; i += 1024) {
+        float4 xv[4];
+        bool has[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k >= 4 && !has_b) break;
+        for (int u = 0; u < 4; ++u) {
+            has[u] = i + 256 * u < n4;
+            xv[u] = has[u] ? row4[i + 256 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int j = 0; j < NG; ++j) { g[j] += xs[k] > t[j]; e[j] += xs[k] == t[j]; }
+        for (int u = 0; u < 4; ++u) {
+            if (!has[u]) continue;
+            const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) { g[j] += xs[k] > t[j]; e[j] += xs[k] == t[j]; }
+            }
         }
     }
     for (int n = 4 * n4 + tid; n < N; n += 256) {
@@ -507,6 +516,57 @@ __device__ __forceinline__ void rank_sweep(const float *__restrict__ row, int64_
     // filtered positions count as -1e8 instead of their score (dataset.py:441)
     for (int64_t f = f_lo + tid; f < f_hi; f += 256) {
         const int col = filt_col[f] - col0;                     // a shard only sees its own candidate columns
+        if (col < 0 || col >= N) continue;
+        const float x = row[col];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            g[j] += (-1e8f > t[j]) - (x > t[j]);
+            e[j] += (-1e8f == t[j]) - (x == t[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < RANK_GROUPS; ++j) { gt[j] = j < NG ? g[j < NG ? j : 0] : 0; eq[j] = j < NG ? e[j < NG ? j : 0] : 0; }
+}
+
+// The same counts with the thread's part of the row already in registers (rows up to RANK_REG_ROW floats): the row
+// loads are issued at kernel entry and overlap the dependent-load chain that finds the true scores
+// (row_ptr -> grp_ptr -> ids -> score), and several group chunks reuse them.
+constexpr int RANK_REG_F4 = 16, RANK_REG_ROW = 256 * 4 * RANK_REG_F4;
+
+template <int NG>
+__device__ __forceinline__ void rank_sweep_regs(const float4 (&rv)[RANK_REG_F4], int n4, float tail_x, bool has_tail, float filt_x,
+                                                bool has_filt, const float *__restrict__ row, int N,
+                                                const int32_t *__restrict__ filt_col, int64_t f_lo, int64_t f_hi, int col0,
+                                                const float *tv, int tid, int (&gt)[RANK_GROUPS], int (&eq)[RANK_GROUPS])
+{
+    float t[NG];
+    int g[NG], e[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) { t[j] = tv[j]; g[j] = 0; e[j] = 0; }
+#pragma unroll
+    for (int u = 0; u < RANK_REG_F4; ++u) {
+        if (tid + 256 * u >= n4) continue;
+        const float xs[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) { g[j] += xs[k] > t[j]; e[j] += xs[k] == t[j]; }
+        }
+    }
+    if (has_tail) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) { g[j] += tail_x > t[j]; e[j] += tail_x == t[j]; }
+    }
+    // filtered positions count as -1e8 instead of their score (dataset.py:441); the first 256 were fetched at entry
+    if (has_filt) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            g[j] += (-1e8f > t[j]) - (filt_x > t[j]);
+            e[j] += (-1e8f == t[j]) - (filt_x == t[j]);
+        }
+    }
+    for (int64_t f = f_lo + 256 + tid; f < f_hi; f += 256) {
+        const int col = filt_col[f] - col0;
         if (col < 0 || col >= N) continue;
         const float x = row[col];
 #pragma unroll
@@ -532,55 +592,87 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
     // Candidate-sharded evaluation runs it twice around two tiny all-reduces:
     //   true_out   : the shard's maximum over each group's ids that fall in [col0, col0 + N)   -> all-reduce(max)
     //   true_in    : global true scores in, counts_out[g] = {#greater, #equal} of this shard   -> all-reduce(sum)
-    __shared__ float tv[RANK_GROUPS];
+    constexpr int TV_CAP = 64;                       // true scores fetched per pass: one dependent-load chain per 64 groups
+    __shared__ float tv[TV_CAP];
     __shared__ int cnt[4][2 * RANK_GROUPS];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *row = scores + (size_t)b * ld;
     const int64_t g_lo = row_ptr[b], g_hi = row_ptr[b + 1];
     const int64_t f_lo = filt_ptr[b], f_hi = filt_ptr[b + 1];
     const int64_t vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
-    for (int64_t g0 = g_lo; g0 < g_hi; g0 += RANK_GROUPS) {
-        const int ng = (int)min((int64_t)RANK_GROUPS, g_hi - g0);
-        if (tid < RANK_GROUPS) {
+    const bool in_regs = vec && N <= RANK_REG_ROW && !true_out;
+    const int n4 = N >> 2;
+    float4 rv[RANK_REG_F4];
+    float tail_x = 0.f, filt_x = 0.f;
+    bool has_tail = false, has_filt = false;
+    if (in_regs) {
+        // everything that does not depend on the true scores is requested now: the row, its (< 4) tail elements and
+        // the scores under the first 256 filter entries
+#pragma unroll
+        for (int u = 0; u < RANK_REG_F4; ++u)
+            rv[u] = tid + 256 * u < n4 ? reinterpret_cast<const float4 *>(row)[tid + 256 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        has_tail = 4 * n4 + tid < N;
+        if (has_tail) tail_x = row[4 * n4 + tid];
+        if (f_lo + tid < f_hi) {
+            const int col = filt_col[f_lo + tid] - col0;
+            has_filt = col >= 0 && col < N;
+            if (has_filt) filt_x = row[col];
+        }
+    }
+    for (int64_t p0 = g_lo; p0 < g_hi; p0 += TV_CAP) {
+        // true scores of up to TV_CAP groups, one thread per group: the grp_ptr -> ids -> score chain is paid once per
+        // pass, not once per 8 groups (rows with many answers set the kernel's duration)
+        const int np = (int)min((int64_t)TV_CAP, g_hi - p0);
+        if (tid < TV_CAP) {
             float t = __builtin_nanf("");                       // unused slots never compare true
-            if (tid < ng) {
+            if (tid < np) {
                 if (true_in) {
-                    t = true_in[g0 + tid];
+                    t = true_in[p0 + tid];
                 } else {
                     t = -INFINITY;
-                    for (int64_t j = grp_ptr[g0 + tid]; j < grp_ptr[g0 + tid + 1]; ++j) {
+                    for (int64_t j = grp_ptr[p0 + tid]; j < grp_ptr[p0 + tid + 1]; ++j) {
                         const int col = ids[j] - col0;
                         if (col >= 0 && col < N) t = fmaxf(t, row[col]);
                     }
-                    if (true_out) true_out[g0 + tid] = t;
+                    if (true_out) true_out[p0 + tid] = t;
                 }
             }
             tv[tid] = t;
         }
         if (true_out) continue;                                 // uniform: phase 1 of the sharded evaluation
         __syncthreads();
-        int gt[RANK_GROUPS], eq[RANK_GROUPS];
-        if (ng == 1)      rank_sweep<1>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
-        else if (ng == 2) rank_sweep<2>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
-        else if (ng <= 4) rank_sweep<4>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
-        else              rank_sweep<8>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        for (int c0 = 0; c0 < np; c0 += RANK_GROUPS) {
+            const int64_t g0 = p0 + c0;
+            const int ng = min(RANK_GROUPS, np - c0);
+            const float *tvc = tv + c0;
+            int gt[RANK_GROUPS], eq[RANK_GROUPS];
+            if (in_regs) {
+                if (ng == 1)      rank_sweep_regs<1>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+                else if (ng == 2) rank_sweep_regs<2>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+                else if (ng <= 4) rank_sweep_regs<4>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+                else              rank_sweep_regs<8>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+            } else if (ng == 1)   rank_sweep<1>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+            else if (ng == 2)     rank_sweep<2>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+            else if (ng <= 4)     rank_sweep<4>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+            else                  rank_sweep<8>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
 #pragma unroll
-        for (int j = 0; j < RANK_GROUPS; ++j) {
-            const int a = wave_sum(gt[j]), e = wave_sum(eq[j]);
-            if ((tid & 63) == 0) { cnt[tid >> 6][2 * j] = a; cnt[tid >> 6][2 * j + 1] = e; }
-        }
-        __syncthreads();
-        if (tid < ng) {
-            const int64_t a = (int64_t)cnt[0][2 * tid] + cnt[1][2 * tid] + cnt[2][2 * tid] + cnt[3][2 * tid];
-            const int64_t e = (int64_t)cnt[0][2 * tid + 1] + cnt[1][2 * tid + 1] + cnt[2][2 * tid + 1] + cnt[3][2 * tid + 1];
-            if (counts_out) {
-                counts_out[2 * (g0 + tid)] = a;
-                counts_out[2 * (g0 + tid) + 1] = e;
-            } else {
-                ranks[g0 + tid] = a + e / 2;
+            for (int j = 0; j < RANK_GROUPS; ++j) {
+                const int a = wave_sum(gt[j]), e = wave_sum(eq[j]);
+                if ((tid & 63) == 0) { cnt[tid >> 6][2 * j] = a; cnt[tid >> 6][2 * j + 1] = e; }
             }
+            __syncthreads();
+            if (tid < ng) {
+                const int64_t a = (int64_t)cnt[0][2 * tid] + cnt[1][2 * tid] + cnt[2][2 * tid] + cnt[3][2 * tid];
+                const int64_t e = (int64_t)cnt[0][2 * tid + 1] + cnt[1][2 * tid + 1] + cnt[2][2 * tid + 1] + cnt[3][2 * tid + 1];
+                if (counts_out) {
+                    counts_out[2 * (g0 + tid)] = a;
+                    counts_out[2 * (g0 + tid) + 1] = e;
+                } else {
+                    ranks[g0 + tid] = a + e / 2;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
