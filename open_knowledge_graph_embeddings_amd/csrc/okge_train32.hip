@@ -22,6 +22,11 @@
 // MODE_SCORE / MODE_STATS (used for slot sizes above 256, where the 64x64 score tile does not fit LDS) stop after
 // the score product and write X, or per-(16-candidate block, row) (max, sum-exp) for the KL loss.
 //
+// Slot sizes above 256 (KB = 32): the two tiles fill 128 KB of LDS, one workgroup per CU.  It runs 8 waves instead of
+// 4 (Tile32Cfg::KS = 2): waves w and w + 4 share a score block, split its contraction and the gradient's columns,
+// and exchange the partial block through LDS (one extra barrier per chunk) -- 184 registers instead of 492, two
+// waves per SIMD: 180 -> 150 us at the DistMult d=512 / N=10000 shape.
+//
 // fp32 MFMA shares the SIMD's vector issue with VALU on gfx950, so the loop is MFMA cycles + VALU cycles; what the
 // second resident workgroup hides is latency (LDS, barriers, HBM), not arithmetic.
 #include <cstdio>
@@ -38,7 +43,14 @@ template <int KB> struct Tile32Cfg {
     static constexpr int LDK = lds_ld(16 * KB);
     static constexpr int NO = 2 * KB;                         // 8-column octets per row
     static constexpr int KEEP_LD = NO < 32 ? 32 : NO;         // keep-flag bytes per row
-    static constexpr int WAVES_PER_SIMD = KB <= 16 ? 2 : 1;   // two workgroups per CU while the tiles fit
+    // Slot sizes above 256: the two tiles take 128 KB of LDS, so only ONE workgroup fits a CU.  It then runs 8 waves
+    // (KS = 2): waves w and w + 4 own the same 16x16 score block, each contracts half of the columns, the partial
+    // blocks are exchanged through LDS, both apply the loss epilogue, and each accumulates the candidate gradient for
+    // ITS half of the columns -- 64 accumulator registers instead of 128, two waves per SIMD instead of one.
+    static constexpr int KS = KB <= 16 ? 1 : 2;
+    static constexpr int THREADS = 256 * KS;
+    static constexpr int QG = 8 * KS;                         // staging: column groups per row (THREADS / 32 rows)
+    static constexpr int WAVES_PER_SIMD = 2;                  // KB <= 16: two workgroups per CU; above: one of 8 waves
 };
 
 #ifdef OKGE_STAMPS
@@ -58,7 +70,7 @@ template <int KB> struct Tile32Cfg {
 #endif
 
 template <int KB, int MODE>
-__global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void fused_tile32_kernel(const FusedArgs a)
+__global__ __launch_bounds__(Tile32Cfg<KB>::THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void fused_tile32_kernel(const FusedArgs a)
 {
 #ifdef OKGE_STAMPS
     unsigned long long wg_t0;
@@ -68,25 +80,30 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Cfg = Tile32Cfg<KB>;
     constexpr int LDK = Cfg::LDK, NO = Cfg::NO, KEEP_LD = Cfg::KEEP_LD;
+    constexpr int KS = Cfg::KS, NTHR = Cfg::THREADS, QG = Cfg::QG;
     constexpr int KQ = KB / 4, KR = KB % 4;
-    constexpr int NOIT = (NO + 7) / 8;
-    constexpr int NQ = 4 * KB, NQIT = (NQ + 7) / 8;       // float4 per row
+    constexpr int KBW = KB / KS, KQW = KQ / KS;          // contraction blocks / gradient column quads of one wave
+    static_assert(KS == 1 || (KB % 8 == 0), "the column split needs whole quads of 16-column blocks per wave");
+    constexpr int NOIT = (NO + QG - 1) / QG;
+    constexpr int NQ = 4 * KB, NQIT = (NQ + QG - 1) / QG;       // float4 per row
     constexpr bool TRAIN = MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL;
     const int d = a.d;
     float *Cs = reinterpret_cast<float *>(smem);              // [32][LDK]   (end: dC stage of half 1)
     float *Qs = Cs + NT32 * LDK;                              // [32][LDK]   (end: dC stage of half 0)
     uint32_t *ybits2 = reinterpret_cast<uint32_t *>(Qs + BC32 * LDK);    // [2][32] label bits, double-buffered by chunk
-    double *red = reinterpret_cast<double *>(ybits2 + 2 * BC32);         // [4]
-    uint8_t *keepb = reinterpret_cast<uint8_t *>(red + 4);               // [32][KEEP_LD] keep flags of the tile
+    double *red = reinterpret_cast<double *>(ybits2 + 2 * BC32);         // [4 * KS]
+    uint8_t *keepb = reinterpret_cast<uint8_t *>(red + 4 * KS);          // [32][KEEP_LD] keep flags of the tile
     uint32_t *posc = reinterpret_cast<uint32_t *>(keepb + NT32 * KEEP_LD);   // [POS_CACHE] (row << 6 | col)
+    v4f *xs = reinterpret_cast<v4f *>(posc + POS_CACHE);                 // KS == 2: [2][4][64] partial score blocks
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, s = lane >> 4;
-    const int nbk = w & 1, half = w >> 1;
+    const int ks = KS == 1 ? 0 : w >> 2, wq = w & 3;     // column half, position in the 2 x 2 block grid
+    const int nbk = wq & 1, half = wq >> 1;
     const int n0 = blockIdx.x * NT32;
     const int b_begin = blockIdx.y * a.b_per_block;
     const int b_end = min(a.B, b_begin + a.b_per_block);
     const bool vec_ok = (d & 3) == 0;
-    const int r8 = tid >> 3, q8 = tid & 7;                    // staging role: row r8, column group q8
+    const int r8 = tid / QG, q8 = tid % QG;                   // staging role: row r8, column group q8
 
     // ---- register-staged query chunk (32 rows x 16*KB): thread holds float4 columns q8 + 8*it of row r8 ------
     v4f qreg[NQIT];
@@ -95,7 +112,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         const float *src = a.Q + (size_t)b * a.ldq;
 #pragma unroll
         for (int it = 0; it < NQIT; ++it) {
-            const int q = min(q8 + 8 * it, NQ - 1);
+            const int q = min(q8 + QG * it, NQ - 1);
             qreg[it] = (b < b_end) ? *reinterpret_cast<const v4f *>(src + 4 * q) : (v4f){0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -112,7 +129,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         v4f v0[NOIT], v1[NOIT];
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
-            const int o = q8 + 8 * it, k = 8 * o;
+            const int o = q8 + QG * it, k = 8 * o;
             v0[it] = (v4f){0.f, 0.f, 0.f, 0.f};
             v1[it] = (v4f){0.f, 0.f, 0.f, 0.f};
             if (o < NO && valid && k < d) {
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         }
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
-            const int o = q8 + 8 * it, k = 8 * o;
+            const int o = q8 + QG * it, k = 8 * o;
             if (o < NO) {
                 uint32_t bits = 0xFFu;
                 if (a.drop_c.enabled) {
@@ -158,14 +175,14 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         pos_lo = a.tile_ptr[blockIdx.x];
         pos_hi = a.tile_ptr[blockIdx.x + 1];
         pos_cached = min(pos_hi - pos_lo, POS_CACHE);
-        for (int i = tid; i < pos_cached; i += FUSED_THREADS)
+        for (int i = tid; i < pos_cached; i += NTHR)
             posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - a.cand_col0 - n0);
         __syncthreads();
     }
 
-    v4f dc[KB];                                      // dC[n = 16nbk + 4s + i][k = grad col(kbi, c)], rows of this half
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) dc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
+    v4f dc[KBW];                                     // dC[n = 16nbk + 4s + i][k = grad col(kbi, c)], rows of this half
+#pragma unroll                                       // (KS == 2: the 16-column blocks KBW*ks .. of the gradient)
+    for (int kb = 0; kb < KBW; ++kb) dc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
     float lsum = 0.f;
 
     int par = 0;
@@ -176,17 +193,17 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         uint32_t *ybits = ybits2 + par * BC32;
 #pragma unroll
         for (int it = 0; it < NQIT; ++it) {
-            const int q = q8 + 8 * it;
+            const int q = q8 + QG * it;
             if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
         }
         if (TRAIN) {
             if (tid < BC32) ybits2[(par ^ 1) * BC32 + tid] = 0u;
-            for (int i = tid; i < pos_cached; i += FUSED_THREADS) {
+            for (int i = tid; i < pos_cached; i += NTHR) {
                 const uint32_t v = posc[i];
                 const int row = (int)(v >> 6) - b0;
                 if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (v & 63u));
             }
-            for (int p = pos_lo + POS_CACHE + tid; p < pos_hi; p += FUSED_THREADS) {      // overflow: rare
+            for (int p = pos_lo + POS_CACHE + tid; p < pos_hi; p += NTHR) {      // overflow: rare
                 const int row = a.pos_row[p] - b0;
                 if (row >= 0 && row < BC32) atomicOr(&ybits[row], 1u << (a.pos_col[p] - a.cand_col0 - n0));
             }
@@ -199,19 +216,19 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         v4f x0 = (v4f){0.f, 0.f, 0.f, 0.f}, x1 = (v4f){0.f, 0.f, 0.f, 0.f};
         {
             // operands are requested TWO rounds ahead: one round is 4 MFMAs = 128 cycles, about one LDS round trip
-            const float *qa = Qs + (16 * half + c) * LDK + 4 * s;
-            const float *cb = Cs + (16 * nbk + c) * LDK + 4 * s;
+            const float *qa = Qs + (16 * half + c) * LDK + 4 * s + 16 * KBW * ks;    // KS == 2: this wave's column half
+            const float *cb = Cs + (16 * nbk + c) * LDK + 4 * s + 16 * KBW * ks;
             v4f a0 = *reinterpret_cast<const v4f *>(qa), b0v = *reinterpret_cast<const v4f *>(cb);
             v4f a1 = a0, b1v = b0v;
-            if (KB > 1) {
+            if (KBW > 1) {
                 a1 = *reinterpret_cast<const v4f *>(qa + 16);
                 b1v = *reinterpret_cast<const v4f *>(cb + 16);
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, KB > 1 ? 4 : 2, 0);   // rounds 0 and 1 operands
+            __builtin_amdgcn_sched_group_barrier(0x100, KBW > 1 ? 4 : 2, 0);   // rounds 0 and 1 operands
 #pragma unroll
-            for (int r = 0; r < KB; ++r) {
+            for (int r = 0; r < KBW; ++r) {
                 v4f a2 = a1, b2v = b1v;
-                if (r + 2 < KB) {
+                if (r + 2 < KBW) {
                     a2 = *reinterpret_cast<const v4f *>(qa + 16 * (r + 2));
                     b2v = *reinterpret_cast<const v4f *>(cb + 16 * (r + 2));
                 }
@@ -225,7 +242,12 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA   (round r)
             }
         }
-        const v4f x = x0 + x1;
+        v4f x = x0 + x1;
+        if (KS == 2) {                                   // the other column half's partial block, through LDS
+            xs[(ks * 4 + wq) * 64 + lane] = x;
+            __syncthreads();
+            x += xs[((ks ^ 1) * 4 + wq) * 64 + lane];    // a + b == b + a: both waves hold the same bits
+        }
         TL_STAMP();   // [1] end of score product
 
         if (MODE == MODE_SCORE) {
@@ -233,7 +255,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int b = b0 + 16 * half + 4 * s + i;
-                if (b < b_end && n < a.N) a.X[(size_t)b * a.ldx + n] = x[i];
+                if (ks == 0 && b < b_end && n < a.N) a.X[(size_t)b * a.ldx + n] = x[i];
             }
             __syncthreads();
             continue;
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
                 const int b = b0 + 16 * half + 4 * s + i;
-                if (c == 0 && b < b_end)
+                if (ks == 0 && c == 0 && b < b_end)
                     reinterpret_cast<float2 *>(a.stats)[(size_t)(2 * blockIdx.x + nbk) * a.Bpad + b] = make_float2(m, se);
             }
             __syncthreads();
@@ -258,13 +280,13 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         }
 
         // B operands (query rows) of the dC product's first step: requested now, consumed after the epilogue
-        const float *qb = Qs + (16 * half + 4 * s) * LDK;
-        v4f pb[KQ > 0 ? KQ : 1];
+        const float *qb = Qs + (16 * half + 4 * s) * LDK + 64 * KQW * ks;       // KS == 2: this wave's gradient columns
+        v4f pb[KQW > 0 ? KQW : 1];
         float pr[KR > 0 ? KR : 1];
 #pragma unroll
-        for (int kq = 0; kq < KQ; ++kq) pb[kq] = *reinterpret_cast<const v4f *>(qb + 64 * kq + 4 * c);
+        for (int kq = 0; kq < KQW; ++kq) pb[kq] = *reinterpret_cast<const v4f *>(qb + 64 * kq + 4 * c);
 #pragma unroll
-        for (int r = 0; r < KR; ++r) pr[r] = qb[64 * KQ + 16 * r + c];
+        for (int r = 0; r < KR; ++r) pr[r] = qb[64 * KQ + 16 * r + c];          // (KR > 0 only with KS == 1)
 
         // ---- loss epilogue: G = dLoss/dX / normalizer, kept in registers --------------------------------------
         v4f g4;
@@ -297,14 +319,14 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
                     l = pos ? -lsm : 0.f;
                     g = __builtin_amdgcn_exp2f(lsm * LOG2E) * a.row_ysum[b] - (pos ? 1.f : 0.f);
                 }
-                lsum += valid ? l : 0.f;
+                lsum += (valid && ks == 0) ? l : 0.f;       // the partner wave sees the same block: count it once
                 g4[i] = valid ? g * a.inv_norm : 0.f;
             }
         }
         TL_STAMP();   // [2] start of dC product
         if (!a.loss_only) {
             // ---- G block -> HBM for dq_kernel: Gt[T][J][n_local][b_local], 4 consecutive batch rows per lane ------
-            {
+            if (ks == 0) {
                 const int t = blockIdx.x, j = b0 >> 5;
                 const size_t blk = (size_t)(t >> 1) * (a.Bpad >> 6) + (j >> 1);
                 const int nl64 = 32 * (t & 1) + 16 * nbk + c, bl64 = 32 * (j & 1) + 16 * half + 4 * s;
@@ -315,17 +337,17 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float av = g4[t];
-                v4f nb[KQ > 0 ? KQ : 1];
+                v4f nb[KQW > 0 ? KQW : 1];
                 float nr[KR > 0 ? KR : 1];
                 if (t + 1 < 4) {
                     const float *brow = qb + (t + 1) * LDK;
 #pragma unroll
-                    for (int kq = 0; kq < KQ; ++kq) nb[kq] = *reinterpret_cast<const v4f *>(brow + 64 * kq + 4 * c);
+                    for (int kq = 0; kq < KQW; ++kq) nb[kq] = *reinterpret_cast<const v4f *>(brow + 64 * kq + 4 * c);
 #pragma unroll
                     for (int r = 0; r < KR; ++r) nr[r] = brow[64 * KQ + 16 * r + c];
                 }
 #pragma unroll
-                for (int kq = 0; kq < KQ; ++kq) {
+                for (int kq = 0; kq < KQW; ++kq) {
                     dc[4 * kq + 0] = mfma16(av, pb[kq][0], dc[4 * kq + 0]);
                     dc[4 * kq + 1] = mfma16(av, pb[kq][1], dc[4 * kq + 1]);
                     dc[4 * kq + 2] = mfma16(av, pb[kq][2], dc[4 * kq + 2]);
@@ -335,12 +357,12 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
                 for (int r = 0; r < KR; ++r) dc[4 * KQ + r] = mfma16(av, pr[r], dc[4 * KQ + r]);
                 if (t + 1 < 4) {
 #pragma unroll
-                    for (int kq = 0; kq < KQ; ++kq) pb[kq] = nb[kq];
+                    for (int kq = 0; kq < KQW; ++kq) pb[kq] = nb[kq];
 #pragma unroll
                     for (int r = 0; r < KR; ++r) pr[r] = nr[r];
-                    __builtin_amdgcn_sched_group_barrier(0x100, KQ + KR, 1);   // next step's ds_reads first
+                    __builtin_amdgcn_sched_group_barrier(0x100, KQW + KR, 1);  // next step's ds_reads first
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, KB, 1);            // then this step's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, KBW, 1);           // then this step's MFMAs
             }
         }
         TL_STAMP();   // [3] end of dC product
@@ -351,12 +373,12 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
         // ---- write-back: both halves stage their partial dC (half 0 -> Qs, half 1 -> Cs), then rows are summed,
         //      masked with the cached dropout flags and added into dE ------------------------------------------------
         if (!a.loss_only) {
-            float *stage = half == 0 ? Qs : Cs;
+            float *stage = (half == 0 ? Qs : Cs) + 64 * KQW * ks;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float *srow = stage + (16 * nbk + 4 * s + i) * LDK;
 #pragma unroll
-                for (int kq = 0; kq < KQ; ++kq)
+                for (int kq = 0; kq < KQW; ++kq)
                     *reinterpret_cast<v4f *>(srow + 64 * kq + 4 * c) =
                         (v4f){dc[4 * kq][i], dc[4 * kq + 1][i], dc[4 * kq + 2][i], dc[4 * kq + 3][i]};
 #pragma unroll
@@ -368,7 +390,12 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
             if (lane == 0) red[w] = ls;
         }
         __syncthreads();
-        if (tid == 0) a.loss_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4 * KS; ++i) tot += red[i];
+            a.loss_partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = tot;
+        }
         const int n = n0 + r8;
         if (!a.loss_only && n < a.N) {
             const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
@@ -380,7 +407,7 @@ __global__ __launch_bounds__(FUSED_THREADS, Tile32Cfg<KB>::WAVES_PER_SIMD) void 
             float *srow = gridDim.y > 1 ? a.dC_slab + ((size_t)blockIdx.y * gridDim.x * NT32 + n) * (16 * KB) : nullptr;
 #pragma unroll
             for (int it = 0; it < NOIT; ++it) {
-                const int o = q8 + 8 * it, k = 8 * o;
+                const int o = q8 + QG * it, k = 8 * o;
                 if (o >= NO || k >= d) continue;
                 v4f v[2];
                 v[0] = *reinterpret_cast<const v4f *>(Qs + r8 * LDK + k) + *reinterpret_cast<const v4f *>(Cs + r8 * LDK + k);
@@ -438,8 +465,8 @@ template <int KB>
 static size_t shmem32()
 {
     using Cfg = Tile32Cfg<KB>;
-    return (size_t)(NT32 + BC32) * Cfg::LDK * sizeof(float) + 2 * BC32 * sizeof(uint32_t) + 4 * sizeof(double) +
-           NT32 * Cfg::KEEP_LD + POS_CACHE * sizeof(uint32_t);
+    return (size_t)(NT32 + BC32) * Cfg::LDK * sizeof(float) + 2 * BC32 * sizeof(uint32_t) + 4 * Cfg::KS * sizeof(double) +
+           NT32 * Cfg::KEEP_LD + POS_CACHE * sizeof(uint32_t) + (Cfg::KS == 2 ? 2 * 4 * 64 * sizeof(v4f) : 0);
 }
 
 template <int KB, int MODE>
@@ -456,11 +483,11 @@ static hipError_t launch32_t(const FusedArgs &a, dim3 grid, hipStream_t st)
     }
     if (std::getenv("OKGE_DEBUG")) {
         int nb = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), FUSED_THREADS, shmem);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), Tile32Cfg<KB>::THREADS, shmem);
         fprintf(stderr, "[okge] fused_tile32<%d,%d>: occupancy %d blocks/CU (err %d), dyn LDS %zu, grid %ux%u\n", KB, MODE,
                 nb, (int)e, shmem, grid.x, grid.y);
     }
-    hipLaunchKernelGGL(k, grid, dim3(FUSED_THREADS), shmem, st, a);
+    hipLaunchKernelGGL(k, grid, dim3(Tile32Cfg<KB>::THREADS), shmem, st, a);
     return hipGetLastError();
 }
 
