@@ -93,11 +93,10 @@ __device__ __forceinline__ void load_cand_tile(float *Cs, uint8_t *keepb, float 
 //   brow : &B[16*s][0] + lane column offset handled here
 // Contraction row of (slot s, step t) is 16*s + t.  A is read 4 steps at a time when A_VEC (A stored with
 // the contraction index contiguous), else one ds_read_b32 per step.
-template <int KB, bool A_VEC>
-__device__ __forceinline__ void grad_product(v4f (&acc)[KB], const float *a_base, int lda, const float *b_base,
-                                             int c)
+template <int KB, bool A_VEC, int LDK = lds_ld(16 * KB)>      // LDK: leading dimension of the B tile (wider than 16*KB when
+__device__ __forceinline__ void grad_product(v4f (&acc)[KB], const float *a_base, int lda, const float *b_base,   // a wave
+                                             int c)                                                                // takes a column range of it)
 {
-    constexpr int LDK = lds_ld(16 * KB);
     constexpr int KQ = KB / 4, KR = KB % 4;
     // b_base points at B[16*s][0].  Operands of step t+1 are requested before the KB MFMAs of step t issue.
     v4f pb[KQ > 0 ? KQ : 1], nb[KQ > 0 ? KQ : 1];
@@ -271,19 +270,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
 // ---- dQ = G . C over a candidate range -------------------------------------------------------------
 // G^T block (64 candidates x 64 batch rows, 16 KB contiguous) and masked
 // candidate tile (64 x 16*KB) of one chunk -> registers
+// slot sizes above 256: the 132 KB candidate tile leaves room for one workgroup per CU; it runs 8 waves, waves w and
+// w + 4 taking the two halves of the output columns (no exchange needed: disjoint outputs, shared G^T operand)
+template <int KB> struct DqCfg {
+    static constexpr int KS = KB <= 16 ? 1 : 2;
+    static constexpr int THREADS = 256 * KS;
+    static constexpr int QG = 8 * KS;                 // staging: column groups per row
+    static constexpr int NO = 2 * KB, NOIT = (NO + QG - 1) / QG;
+    static constexpr int GV = 4 / KS;                 // float4 of the G^T block per thread
+};
+
 template <int KB>
-__device__ __forceinline__ void dq_prefetch(v4f (&gv)[4], v4f (&cv)[4 * ((2 * KB + 7) / 8)],
+__device__ __forceinline__ void dq_prefetch(v4f (&gv)[DqCfg<KB>::GV], v4f (&cv)[4 * DqCfg<KB>::NOIT],
                                             const float *__restrict__ g_blk, const float *__restrict__ cm, int tid)
 {
-    constexpr int NO = 2 * KB, NOIT = (NO + 7) / 8;
+    using Cfg = DqCfg<KB>;
+    constexpr int NO = Cfg::NO, NOIT = Cfg::NOIT, QG = Cfg::QG;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) gv[it] = *reinterpret_cast<const v4f *>(g_blk + (size_t)(tid + it * FUSED_THREADS) * 4);
+    for (int it = 0; it < Cfg::GV; ++it) gv[it] = *reinterpret_cast<const v4f *>(g_blk + (size_t)(tid + it * Cfg::THREADS) * 4);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        const int r = (tid >> 3) + 32 * pass;
+        const int r = tid / QG + 32 * pass;
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
-            const int o = min((tid & 7) + 8 * it, NO - 1);   // clamped: surplus lanes reload the last octet
+            const int o = min(tid % QG + QG * it, NO - 1);   // clamped: surplus lanes reload the last octet
             cv[(2 * pass) * NOIT + it] = *reinterpret_cast<const v4f *>(cm + (size_t)r * (16 * KB) + 8 * o);
             cv[(2 * pass + 1) * NOIT + it] = *reinterpret_cast<const v4f *>(cm + (size_t)r * (16 * KB) + 8 * o + 4);
         }
@@ -294,16 +304,21 @@ constexpr int LDGT = 68;   // G^T tile leading dimension (16-byte aligned rows; 
                            // so its 2-way conflict between slots 16 rows apart is irrelevant)
 
 template <int KB>
-__global__ __launch_bounds__(FUSED_THREADS) void dq_kernel(const DqArgs a)
+__global__ __launch_bounds__(DqCfg<KB>::THREADS) void dq_kernel(const DqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Cfg = DqCfg<KB>;
     constexpr int LDK = lds_ld(16 * KB);
-    constexpr int KQ = KB / 4, KR = KB % 4;
-    constexpr int NO = 2 * KB, NOIT = (NO + 7) / 8;
+    constexpr int KS = Cfg::KS, NTHR = Cfg::THREADS, QG = Cfg::QG;
+    constexpr int KBW = KB / KS;                      // 16-column output blocks of one wave
+    constexpr int KQ = KBW / 4, KR = KBW % 4;
+    static_assert(KS == 1 || KB % 8 == 0, "the column split needs whole quads of 16-column blocks per wave");
+    constexpr int NO = Cfg::NO, NOIT = Cfg::NOIT;
     float *Cs = reinterpret_cast<float *>(smem);      // [NT][LDK]   masked candidate rows
     float *Gt = Cs + NT * LDK;                        // [NT (n)][LDGT] : G^T tile, 64 batch rows wide
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, s = lane >> 4;
+    const int ks = KS == 1 ? 0 : w >> 2, wq = w & 3;  // column half, 16-row block of the 64 batch rows
     const int split = blockIdx.x % a.nsplit, bblk = blockIdx.x / a.nsplit;
     const int b0 = bblk * BC;
     const int nJ = a.Bpad / BC;
@@ -311,27 +326,27 @@ __global__ __launch_bounds__(FUSED_THREADS) void dq_kernel(const DqArgs a)
     const int ch_lo = (int)((int64_t)split * nchunks / a.nsplit);
     const int ch_hi = (int)((int64_t)(split + 1) * nchunks / a.nsplit);
 
-    v4f acc[KB];                                      // dQ[b = b0 + 16w + 4s + i][k = grad_col(kbi, c)]
+    v4f acc[KBW];                                     // dQ[b = b0 + 16wq + 4s + i][k = 16*KBW*ks + grad_col(kbi, c)]
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) acc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < KBW; ++kb) acc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     // register-staged prefetch: the next chunk's G block and masked candidate tile are in flight during the MFMAs
-    v4f gv[4], cv[4 * NOIT];         // cv[(2*pass + half) * NOIT + it]
+    v4f gv[Cfg::GV], cv[4 * NOIT];   // cv[(2*pass + half) * NOIT + it]
     auto g_block = [&](int ch) { return a.G + ((size_t)ch * nJ + bblk) * 4096; };
     if (ch_lo < ch_hi) dq_prefetch<KB>(gv, cv, g_block(ch_lo), a.Cm + (size_t)ch_lo * NT * (16 * KB), tid);
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
         // G^T block -> LDS (float4 number f: candidate f >> 4, batch rows 4 * (f & 15) ..)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int f = tid + it * FUSED_THREADS;
+        for (int it = 0; it < Cfg::GV; ++it) {
+            const int f = tid + it * NTHR;
             *reinterpret_cast<v4f *>(Gt + (f >> 4) * LDGT + 4 * (f & 15)) = gv[it];
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
-            const int r = (tid >> 3) + 32 * pass;
+            const int r = tid / QG + 32 * pass;
 #pragma unroll
             for (int it = 0; it < NOIT; ++it) {
-                const int o = (tid & 7) + 8 * it;
+                const int o = tid % QG + QG * it;
                 if (o < NO) {
                     *reinterpret_cast<v4f *>(Cs + r * LDK + 8 * o) = cv[(2 * pass) * NOIT + it];
                     *reinterpret_cast<v4f *>(Cs + r * LDK + 8 * o + 4) = cv[(2 * pass + 1) * NOIT + it];
@@ -340,13 +355,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void dq_kernel(const DqArgs a)
         }
         __syncthreads();
         if (ch + 1 < ch_hi) dq_prefetch<KB>(gv, cv, g_block(ch + 1), a.Cm + (size_t)(ch + 1) * NT * (16 * KB), tid);
-        // A[i = b][slot s, step t] = G^T[n = 16s + t][b = 16w + c] ; B[slot][k] = C[n = 16s + t][k]
-        grad_product<KB, false>(acc, Gt + 16 * s * LDGT + 16 * w + c, LDGT, Cs + 16 * s * LDK, c);
+        // A[i = b][slot s, step t] = G^T[n = 16s + t][b = 16wq + c] ; B[slot][k] = C[n = 16s + t][k of this wave's half]
+        grad_product<KBW, false, LDK>(acc, Gt + 16 * s * LDGT + 16 * wq + c, LDGT, Cs + 16 * s * LDK + 16 * KBW * ks, c);
         __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        float *dst = a.slab + ((size_t)split * a.Bpad + b0 + 16 * w + 4 * s + i) * a.ldq;
+        float *dst = a.slab + ((size_t)split * a.Bpad + b0 + 16 * wq + 4 * s + i) * a.ldq + 16 * KBW * ks;
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq)
             *reinterpret_cast<v4f *>(dst + 64 * kq + 4 * c) =
@@ -416,7 +431,7 @@ static hipError_t launch_dq_t(const DqArgs &a, int grid_x, size_t shmem, hipStre
         if (e != hipSuccess) return e;
         configured = shmem;
     }
-    hipLaunchKernelGGL(k, dim3(grid_x), dim3(FUSED_THREADS), shmem, st, a);
+    hipLaunchKernelGGL(k, dim3(grid_x), dim3(DqCfg<KB>::THREADS), shmem, st, a);
     return hipGetLastError();
 }
 
