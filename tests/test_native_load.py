@@ -49,3 +49,14 @@ def test_hotpath_refuses_cpu():
     from open_knowledge_graph_embeddings_amd.hotpath import HotPath
     with pytest.raises(OkgeError):
         HotPath("cpu")
+
+
+def test_integration_doc_maps_every_entry_point():
+    """INTEGRATION.md is the binding guide: every function include/okge.h declares appears in its table"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "okge.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    declared = sorted(set(re.findall(r"\b(okge_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 30
+    assert [f for f in declared if f not in doc] == []
