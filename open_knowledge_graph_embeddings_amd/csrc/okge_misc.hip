@@ -592,12 +592,14 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
     // Candidate-sharded evaluation runs it twice around two tiny all-reduces:
     //   true_out   : the shard's maximum over each group's ids that fall in [col0, col0 + N)   -> all-reduce(max)
     //   true_in    : global true scores in, counts_out[g] = {#greater, #equal} of this shard   -> all-reduce(sum)
-    constexpr int TV_CAP = 64;                       // true scores fetched per pass: one dependent-load chain per 64 groups
-    __shared__ float tv[TV_CAP];
+    // blockIdx.y strides over the row's chunks of 8 answer groups: rows with many answers (they set the kernel's
+    // duration) are spread over gridDim.y workgroups, the others leave at once
+    __shared__ float tv[RANK_GROUPS];
     __shared__ int cnt[4][2 * RANK_GROUPS];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t g_lo = row_ptr[b] + (int64_t)RANK_GROUPS * blockIdx.y, g_hi = row_ptr[b + 1];
+    if (g_lo >= g_hi) return;
     const float *row = scores + (size_t)b * ld;
-    const int64_t g_lo = row_ptr[b], g_hi = row_ptr[b + 1];
     const int64_t f_lo = filt_ptr[b], f_hi = filt_ptr[b + 1];
     const int64_t vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(scores) & 15) == 0);
     const bool in_regs = vec && N <= RANK_REG_ROW && !true_out;
@@ -619,60 +621,53 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
             if (has_filt) filt_x = row[col];
         }
     }
-    for (int64_t p0 = g_lo; p0 < g_hi; p0 += TV_CAP) {
-        // true scores of up to TV_CAP groups, one thread per group: the grp_ptr -> ids -> score chain is paid once per
-        // pass, not once per 8 groups (rows with many answers set the kernel's duration)
-        const int np = (int)min((int64_t)TV_CAP, g_hi - p0);
-        if (tid < TV_CAP) {
+    for (int64_t g0 = g_lo; g0 < g_hi; g0 += (int64_t)RANK_GROUPS * gridDim.y) {
+        const int ng = (int)min((int64_t)RANK_GROUPS, g_hi - g0);
+        if (tid < RANK_GROUPS) {
             float t = __builtin_nanf("");                       // unused slots never compare true
-            if (tid < np) {
+            if (tid < ng) {
                 if (true_in) {
-                    t = true_in[p0 + tid];
+                    t = true_in[g0 + tid];
                 } else {
                     t = -INFINITY;
-                    for (int64_t j = grp_ptr[p0 + tid]; j < grp_ptr[p0 + tid + 1]; ++j) {
+                    for (int64_t j = grp_ptr[g0 + tid]; j < grp_ptr[g0 + tid + 1]; ++j) {
                         const int col = ids[j] - col0;
                         if (col >= 0 && col < N) t = fmaxf(t, row[col]);
                     }
-                    if (true_out) true_out[p0 + tid] = t;
+                    if (true_out) true_out[g0 + tid] = t;
                 }
             }
             tv[tid] = t;
         }
         if (true_out) continue;                                 // uniform: phase 1 of the sharded evaluation
         __syncthreads();
-        for (int c0 = 0; c0 < np; c0 += RANK_GROUPS) {
-            const int64_t g0 = p0 + c0;
-            const int ng = min(RANK_GROUPS, np - c0);
-            const float *tvc = tv + c0;
-            int gt[RANK_GROUPS], eq[RANK_GROUPS];
-            if (in_regs) {
-                if (ng == 1)      rank_sweep_regs<1>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
-                else if (ng == 2) rank_sweep_regs<2>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
-                else if (ng <= 4) rank_sweep_regs<4>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
-                else              rank_sweep_regs<8>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
-            } else if (ng == 1)   rank_sweep<1>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
-            else if (ng == 2)     rank_sweep<2>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
-            else if (ng <= 4)     rank_sweep<4>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
-            else                  rank_sweep<8>(row, vec, N, filt_col, f_lo, f_hi, col0, tvc, tid, gt, eq);
+        int gt[RANK_GROUPS], eq[RANK_GROUPS];
+        if (in_regs) {
+            if (ng == 1)      rank_sweep_regs<1>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+            else if (ng == 2) rank_sweep_regs<2>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+            else if (ng <= 4) rank_sweep_regs<4>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+            else              rank_sweep_regs<8>(rv, n4, tail_x, has_tail, filt_x, has_filt, row, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        } else if (ng == 1)   rank_sweep<1>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        else if (ng == 2)     rank_sweep<2>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        else if (ng <= 4)     rank_sweep<4>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
+        else                  rank_sweep<8>(row, vec, N, filt_col, f_lo, f_hi, col0, tv, tid, gt, eq);
 #pragma unroll
-            for (int j = 0; j < RANK_GROUPS; ++j) {
-                const int a = wave_sum(gt[j]), e = wave_sum(eq[j]);
-                if ((tid & 63) == 0) { cnt[tid >> 6][2 * j] = a; cnt[tid >> 6][2 * j + 1] = e; }
-            }
-            __syncthreads();
-            if (tid < ng) {
-                const int64_t a = (int64_t)cnt[0][2 * tid] + cnt[1][2 * tid] + cnt[2][2 * tid] + cnt[3][2 * tid];
-                const int64_t e = (int64_t)cnt[0][2 * tid + 1] + cnt[1][2 * tid + 1] + cnt[2][2 * tid + 1] + cnt[3][2 * tid + 1];
-                if (counts_out) {
-                    counts_out[2 * (g0 + tid)] = a;
-                    counts_out[2 * (g0 + tid) + 1] = e;
-                } else {
-                    ranks[g0 + tid] = a + e / 2;
-                }
-            }
-            __syncthreads();
+        for (int j = 0; j < RANK_GROUPS; ++j) {
+            const int a = wave_sum(gt[j]), e = wave_sum(eq[j]);
+            if ((tid & 63) == 0) { cnt[tid >> 6][2 * j] = a; cnt[tid >> 6][2 * j + 1] = e; }
         }
+        __syncthreads();
+        if (tid < ng) {
+            const int64_t a = (int64_t)cnt[0][2 * tid] + cnt[1][2 * tid] + cnt[2][2 * tid] + cnt[3][2 * tid];
+            const int64_t e = (int64_t)cnt[0][2 * tid + 1] + cnt[1][2 * tid + 1] + cnt[2][2 * tid + 1] + cnt[3][2 * tid + 1];
+            if (counts_out) {
+                counts_out[2 * (g0 + tid)] = a;
+                counts_out[2 * (g0 + tid) + 1] = e;
+            } else {
+                ranks[g0 + tid] = a + e / 2;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -828,7 +823,7 @@ hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int
                         hipStream_t st)
 {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ranks_kernel, dim3(B), dim3(256), 0, st, scores, ld, N, filt_ptr, filt_col, row_ptr, grp_ptr,
+    hipLaunchKernelGGL(ranks_kernel, dim3(B, 4), dim3(256), 0, st, scores, ld, N, filt_ptr, filt_col, row_ptr, grp_ptr,
                        ids, ranks, col0, true_in, true_out, counts_out);
     return hipGetLastError();
 }
