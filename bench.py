@@ -228,22 +228,20 @@ def main():
         eb = to_dev_batch(hb, w, dev)
         t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
         csr = [t(hb[k]) for k in ("filt_ptr", "filt_col", "row_ptr", "grp_ptr", "ids")]
-        eng = step.engine
-        scores = eng.score(Et, Rt, w.scorer, eb)
-        for _ in range(3):
-            eng.score(Et, Rt, w.scorer, eb, out=scores)
-            ranks = eng.filtered_ranks(scores, *csr)
+        from open_knowledge_graph_embeddings_amd.dataset import CollatedBatch
+        from open_knowledge_graph_embeddings_amd.evaluate import PipelinedEvaluator
+        cb = CollatedBatch(eb, float(w.B * w.N), float(hb["n_pos"]), w.N, row_ptr=csr[2], grp_ptr=csr[3], ids=csr[4],
+                           filt_ptr=csr[0], filt_col=csr[1])
+        ev_run = PipelinedEvaluator(Et, Rt, w.scorer, engine=step.engine)
+        ev_run.run([cb] * 4)
         torch.cuda.synchronize()
+        n_it = 40
         t0 = time.perf_counter()
-        n_it = 30
-        for _ in range(n_it):
-            eng.score(Et, Rt, w.scorer, eb, out=scores)
-            ranks = eng.filtered_ranks(scores, *csr)
+        res, n_groups = ev_run.run([cb] * n_it)           # score on one stream, ranks + meters on another (evaluate.py)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        r = ranks.cpu().numpy()
-        ev = {"ms_per_batch": 1e3 * el / n_it, "prefixes_per_s": w.B * n_it / el, "groups": int(r.shape[0]),
-              "mrr_random_init": float((1.0 / (r + 1.0)).mean())}
+        ev = {"ms_per_batch": 1e3 * el / n_it, "prefixes_per_s": w.B * n_it / el, "groups": n_groups // n_it,
+              "mrr": res["mrr"].avg}
 
     if rank != 0:
         if dist is not None:

@@ -340,6 +340,20 @@ int okge_filtered_ranks(const float *scores, int64_t ld_scores, int32_t B, int32
                         const int64_t *filt_ptr, const int32_t *filt_col,
                         const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, void *stream);
+/* acc[7] (DEVICE doubles) += {#groups, sum 1/(rank+1), sum rank, #rank<1, #rank<3, #rank<10, #rank<50}: the MRR / MR /
+ * Hits@k meters of compute_metrics (dataset.py:447-452, utils/metrics.py) accumulated on the device. */
+int okge_rank_metrics(const int64_t *ranks, int64_t n, double *acc, void *stream);
+/* One evaluation batch in ONE call, pipelined over two streams: okge_score_prefixes on `stream`, then
+ * okge_filtered_ranks + okge_rank_metrics on `rank_stream` (may equal `stream`).  The library orders the two with its
+ * own events and makes a later call that reuses the same `scores` buffer wait until that buffer's ranks are counted, so
+ * a caller alternating two score buffers gets batch i's ranking overlapped with batch i+1's scoring (scoring is
+ * compute-bound, ranking a chain of memory round trips).  Replaces Trainer.evaluate's per-batch body
+ * (trainer.py:258-272, 363-369). */
+int okge_evaluate_batch(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                        const int64_t *filt_ptr, const int32_t *filt_col, const int64_t *row_ptr,
+                        const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, float *scores, int64_t ld_scores,
+                        int64_t *ranks, double *acc, void *workspace, size_t workspace_bytes, void *stream,
+                        void *rank_stream);
 /* The same rank rule with the candidate columns [col0, col0 + n_local) of every row held by this rank
  * (scores: B x n_local; filter columns and group ids stay positions in the FULL candidate list):
  * true_out[g] = max over the group's ids inside the local range (-inf if none)       -> all-reduce(max)

@@ -714,6 +714,66 @@ int okge_filtered_ranks(const float *scores, int64_t ld_scores, int32_t B, int32
     return OKGE_OK;
 }
 
+int okge_rank_metrics(const int64_t *ranks, int64_t n, double *acc, void *stream)
+{
+    if (!ranks || !acc || n < 0) return fail(OKGE_ERR_INVALID, "bad rank_metrics arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("rank_metrics", st);
+    hipError_t e = launch_rank_metrics(ranks, n, acc, st);
+    if (e != hipSuccess) return fail_hip(e, "rank_metrics");
+    return OKGE_OK;
+}
+
+// One evaluation batch on two streams: scores on `stream`, ranks + meters on `rank_stream`, ordered by events the
+// library owns.  A score buffer is reused only after the ranks of the batch that last used it are counted.
+namespace {
+struct EvalSlot { const float *buf; hipEvent_t scored, ranked; bool used; };
+std::mutex g_eval_mu;
+std::vector<EvalSlot> g_eval_slots;
+EvalSlot &eval_slot(const float *buf)
+{
+    for (auto &sl : g_eval_slots)
+        if (sl.buf == buf) return sl;
+    EvalSlot sl{buf, nullptr, nullptr, false};
+    (void)hipEventCreateWithFlags(&sl.scored, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&sl.ranked, hipEventDisableTiming);
+    g_eval_slots.push_back(sl);
+    return g_eval_slots.back();
+}
+}  // namespace
+
+int okge_evaluate_batch(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                        const int64_t *filt_ptr, const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr,
+                        const int32_t *ids, int64_t n_groups, float *scores, int64_t ld_scores, int64_t *ranks, double *acc,
+                        void *workspace, size_t workspace_bytes, void *stream, void *rank_stream)
+{
+    if (!ranks || !acc || n_groups < 0) return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
+    hipStream_t s0 = reinterpret_cast<hipStream_t>(stream), s1 = reinterpret_cast<hipStream_t>(rank_stream);
+    std::lock_guard<std::mutex> lk(g_eval_mu);
+    EvalSlot &sl = eval_slot(scores);
+    hipError_t e;
+    if (sl.used && s0 != s1) {
+        e = hipStreamWaitEvent(s0, sl.ranked, 0);
+        if (e != hipSuccess) return fail_hip(e, "wait for the buffer's previous ranks");
+    }
+    if (int rc = okge_score_prefixes(t, batch, cand, scores, ld_scores, workspace, workspace_bytes, stream)) return rc;
+    if (s0 != s1) {
+        e = hipEventRecord(sl.scored, s0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s1, sl.scored, 0);
+        if (e != hipSuccess) return fail_hip(e, "order ranks after scores");
+    }
+    const int32_t B = batch->n_po + batch->n_sp;
+    if (int rc = okge_filtered_ranks(scores, ld_scores, B, cand->n, filt_ptr, filt_col, row_ptr, grp_ptr, ids, ranks, rank_stream))
+        return rc;
+    if (int rc = okge_rank_metrics(ranks, n_groups, acc, rank_stream)) return rc;
+    if (s0 != s1) {
+        e = hipEventRecord(sl.ranked, s1);
+        if (e != hipSuccess) return fail_hip(e, "record ranks done");
+        sl.used = true;
+    }
+    return OKGE_OK;
+}
+
 int okge_group_true_scores(const float *scores, int64_t ld_scores, int32_t B, int32_t col0, int32_t n_local,
                            const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids, float *true_out,
                            void *stream)

@@ -98,6 +98,7 @@ hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16
                             int cand_first, int exclusive, int grads_zero, float *dE, hipStream_t st);
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st);
+hipError_t launch_rank_metrics(const int64_t *ranks, int64_t n, double *acc, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, int col0, const float *true_in, float *true_out, int64_t *counts_out,

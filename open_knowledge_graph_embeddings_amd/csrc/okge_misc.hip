@@ -671,6 +671,28 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float *__restrict__ sc
     }
 }
 
+// acc[0..6] += {#groups, sum 1/(rank+1), sum rank, #rank<1, #rank<3, #rank<10, #rank<50}: the meters of compute_metrics
+// (dataset.py:447-452) kept on the device, so that evaluation batches need no host round trip
+__global__ __launch_bounds__(256) void rank_metrics_kernel(const int64_t *__restrict__ ranks, int64_t n, double *__restrict__ acc)
+{
+    __shared__ double red[4][7];
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int64_t r = ranks[i];
+        v[0] += 1.0;
+        v[1] += (double)(1.0f / (float)(r + 1));       // fp32 reciprocal like the reference's (1/(rank+1).float())
+        v[2] += (double)r;
+        v[3] += r < 1; v[4] += r < 3; v[5] += r < 10; v[6] += r < 50;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double t = wave_sum(v[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) acc[threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 // Per-triple score of already encoded rows, Hadamard form (model.py:231-238, :276): one wave per triple.
 __global__ __launch_bounds__(256) void score_triples_kernel(const float *__restrict__ S, int64_t lds_,
                                                             const float *__restrict__ Rr, int64_t ldr,
@@ -814,6 +836,13 @@ hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p
     const int blocks = (int)std::min((int64_t)16384, (n4 + 255) / 256);
     const AdagradSeg a{p0, g0, s0, n0}, b{p1, g1, s1, n1};
     hipLaunchKernelGGL(adagrad2_kernel, dim3(blocks), dim3(256), 0, st, a, b, lr, wd, eps, zero_grad);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_metrics(const int64_t *ranks, int64_t n, double *acc, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3(1), dim3(256), 0, st, ranks, n, acc);
     return hipGetLastError();
 }
 

@@ -1,0 +1,77 @@
+"""Evaluation loop: `Trainer.evaluate` -> `compute_one_batch(training=False)` -> `compute_metrics`
+(openkge/trainer.py:363-369, :258-272; openkge/dataset.py:423-453) over the HIP kernels, with the two kernels of a batch
+on two streams: scoring a batch is compute-bound, ranking it is a chain of memory round trips, so ranking batch i
+overlaps scoring batch i+1 (two score buffers).  Meters accumulate on the device; one host read at the end."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as N
+from . import hotpath as H
+from .metrics import MetricResult
+
+
+class PipelinedEvaluator:
+    def __init__(self, E, R, scorer, engine=None):
+        self.E, self.R, self.scorer = E, R, scorer
+        self.device = E.device
+        self.engine = engine or H.HotPath(self.device)
+        self.rank_stream = torch.cuda.Stream(device=self.device)
+        self._bufs = [None, None]
+        self._ranks = [None, None]
+        # the descriptors of a call are built once and only their per-batch pointers change: at ~60 us of device work
+        # per batch the Python cost of filling three ctypes structs is what decides whether the two streams overlap
+        self._t = self.engine._tables(E, R, scorer)
+        self._pb, self._c = N.PrefixBatch(), N.Candidates()
+        self._rs = ctypes.c_void_p(self.rank_stream.cuda_stream)
+
+    def _buffer(self, slot, B, n):
+        ld = (n + 3) // 4 * 4
+        buf = self._bufs[slot]
+        if buf is None or buf.shape[0] < B or buf.shape[1] != ld:
+            buf = self._bufs[slot] = torch.empty((B, ld), dtype=torch.float32, device=self.device)
+        return buf[:B, :n]
+
+    def run(self, batches):
+        """batches: iterable of dataset.CollatedBatch built with is_training_data=False.
+        -> (MetricResult with mrr / mr / h1 / h3 / h10 / h50 filled like compute_metrics, number of answer groups)"""
+        eng = self.engine
+        acc = torch.zeros(7, dtype=torch.float64, device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        keep = None
+        for i, cb in enumerate(batches):
+            slot = i & 1
+            x = self._buffer(slot, cb.batch.B, cb.n_cand)
+            n_groups = int(cb.grp_ptr.numel()) - 1
+            if self._ranks[slot] is None or self._ranks[slot].numel() < n_groups:
+                self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
+            for t in (cb.filt_ptr, cb.filt_col, cb.row_ptr, cb.grp_ptr, cb.ids):
+                t.record_stream(self.rank_stream)                # read there after `cb` may have gone out of scope here
+            # one library call: scores on the current stream, ranks + meters on rank_stream, ordered by library events;
+            # the buffer of batch i-2 is reused only after its ranks were counted
+            b, pb, c = cb.batch, self._pb, self._c
+            pb.po_rel, pb.po_obj = (b.po_rel.data_ptr(), b.po_obj.data_ptr()) if b.po_rel is not None else (None, None)
+            pb.sp_subj, pb.sp_rel = (b.sp_subj.data_ptr(), b.sp_rel.data_ptr()) if b.sp_subj is not None else (None, None)
+            pb.n_po, pb.n_sp = b.n_po, b.n_sp
+            c.ids = b.cand_ids.data_ptr() if b.cand_ids is not None else None
+            c.first_id, c.n = b.cand_first, cb.n_cand
+            ws = eng.workspace(b.B, cb.n_cand, self._t.d)
+            N.check(eng.lib.okge_evaluate_batch(ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c),
+                                                cb.filt_ptr.data_ptr(), cb.filt_col.data_ptr() if cb.filt_col.numel() else None,
+                                                cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(), cb.ids.data_ptr(), n_groups,
+                                                x.data_ptr(), x.stride(0), self._ranks[slot].data_ptr(), acc.data_ptr(),
+                                                ws.data_ptr(), eng._ws_bytes, eng._stream(), self._rs), "okge_evaluate_batch")
+            keep = cb
+        main.wait_stream(self.rank_stream)
+        a = acc.cpu().tolist()
+        del keep
+        n = int(a[0])
+        out = MetricResult()
+        if n:
+            out["mrr"].update(a[1] / n, n)
+            out["mr"].update(a[2] / n, n)
+            for k, v in (("h1", a[3]), ("h3", a[4]), ("h10", a[5]), ("h50", a[6])):
+                out[k].update(v / n, n)
+        return out, n

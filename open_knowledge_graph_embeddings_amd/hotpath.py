@@ -370,6 +370,26 @@ class HotPath:
                                              ranks.data_ptr(), self._stream()), "okge_filtered_ranks")
         return ranks
 
+    def evaluate_batch(self, E, R, scorer, batch: PrefixBatch, filt_ptr, filt_col, row_ptr, grp_ptr, ids, scores, ranks,
+                       acc, rank_stream):
+        """score (current stream) -> filtered ranks -> meters (rank_stream) in one library call; `scores` (B, >=N) and
+        `ranks` (>= n_groups int64) are caller buffers, `acc` 7 device doubles."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E, R, scorer)
+        ws = self.workspace(batch.B, c.n, t.d)
+        n_groups = int(grp_ptr.numel()) - 1
+        N.check(self.lib.okge_evaluate_batch(ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), filt_ptr.data_ptr(),
+                                             _ptr(filt_col), row_ptr.data_ptr(), grp_ptr.data_ptr(), ids.data_ptr(),
+                                             n_groups, scores.data_ptr(), scores.stride(0), ranks.data_ptr(),
+                                             acc.data_ptr(), ws.data_ptr(), self._ws_bytes, self._stream(),
+                                             ctypes.c_void_p(rank_stream.cuda_stream)), "okge_evaluate_batch")
+        del keep
+
+    def rank_metrics(self, ranks, acc):
+        """acc (7 device doubles) += {n, sum 1/(r+1), sum r, #r<1, #r<3, #r<10, #r<50}"""
+        N.check(self.lib.okge_rank_metrics(ranks.data_ptr(), int(ranks.numel()), acc.data_ptr(), self._stream()),
+                "okge_rank_metrics")
+
     def group_true_scores(self, scores, col0, row_ptr, grp_ptr, ids):
         """float32 per answer group: max score over the group's ids inside columns [col0, col0 + n_local)."""
         out = torch.empty(int(grp_ptr.numel()) - 1, dtype=torch.float32, device=self.device)

@@ -308,3 +308,8 @@ def test_toy_kg_end_to_end_training_improves_mrr(okge_lib):
     after = mrr()
     first, last = losses[0], losses[-1]
     assert before < 0.25 and after > 0.8 and last < 0.5 * first, (before, after, first, last)
+    # the two-stream evaluator (score on one stream, ranks + device-side meters on another) agrees
+    from open_knowledge_graph_embeddings_amd.evaluate import PipelinedEvaluator
+    res, n_groups = PipelinedEvaluator(E, R, "complex", engine=hp).run(valid)
+    assert abs(res["mrr"].avg - after) < 1e-6 and n_groups == res["mrr"].count > 0
+    assert 0.0 <= res["h1"].avg <= res["h3"].avg <= res["h10"].avg <= res["h50"].avg <= 1.0 and res["mr"].avg >= 0
