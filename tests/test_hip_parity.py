@@ -290,7 +290,7 @@ def test_repeated_candidate_ids_accumulate(hp, grads_zero):
 
 
 def test_b_split_path(hp, monkeypatch):
-    """Few candidate tiles -> the batch is split across blockIdx.y and dC goes through atomics."""
+    """Few candidate tiles -> the batch is split across blockIdx.y; partial dC rows go to slabs summed by dc_reduce."""
     E, R, z, cand, y = random_problem(5, 300, 11, 64, 200, 184, 100)
     ref = oracle_step("complex", E, R, z, cand, y)
     Et, Rt = dev(E), dev(R)
