@@ -88,3 +88,44 @@ def test_random_shape(okge_lib, monkeypatch, i):
     assert abs(loss.item() - ref["loss"]) <= 5e-5 * abs(ref["loss"]) + 1e-5, (info, loss.item(), ref["loss"])
     for mine, r in ((dE, ref["dE"]), (dR, ref["dR"])):
         np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=5e-5 * np.abs(r).max() + 5e-7, err_msg=str(info))   # + exp/log noise where the true gradient is 0 (600 further seeds pass)
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_ranks(okge_lib, i):
+    """filtered ranks on random score matrices with forced ties, multi-mention groups, many groups per row, long filter
+    lists, unaligned / long rows (register and streaming sweeps): bit-equal to the oracle's rule."""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    rng = np.random.default_rng(9100 + i)
+    B = int(rng.integers(1, 40))
+    N = int(rng.choice([5, 63, 64, 1000, 4099, 14541, 16384, 16385, 20011]))
+    pad = int(rng.choice([0, 0, 1, 3]))                                  # leading dimension not a multiple of 4: scalar path
+    x = np.round(rng.standard_normal((B, N)).astype(np.float32) * 2, int(rng.choice([0, 1, 3])))      # few decimals -> ties
+    row_ptr, grp_ptr, ids, filt_ptr, filt_col = [0], [0], [], [0], []
+    for b in range(B):
+        for _ in range(int(rng.choice([1, 1, 2, 3, 9, 20, 70]))):
+            ids += rng.integers(0, N, int(rng.integers(1, 4))).tolist()
+            grp_ptr.append(len(ids))
+        row_ptr.append(len(grp_ptr) - 1)
+        nf = int(rng.choice([0, 3, 40, 300, 700]))
+        filt_col += sorted(set(rng.integers(0, N, nf).tolist()))
+        filt_ptr.append(len(filt_col))
+    filt = np.zeros((B, N), bool)
+    for b in range(B):
+        filt[b, filt_col[filt_ptr[b]:filt_ptr[b + 1]]] = True
+    ref = ko.filtered_ranks(x, filt, np.asarray(row_ptr), np.asarray(grp_ptr), np.asarray(ids, np.int32))
+    ld = (N + 3) // 4 * 4 + pad
+    buf = torch.zeros((B, ld), device="cuda:0")
+    buf[:, :N] = torch.from_numpy(x).cuda()
+    t = lambda a, dt: torch.tensor(a, dtype=dt, device="cuda:0")           # noqa: E731
+    hp = H.HotPath("cuda:0")
+    got = hp.filtered_ranks(buf[:, :N], t(filt_ptr, torch.int64), t(filt_col or [0], torch.int32), t(row_ptr, torch.int64),
+                            t(grp_ptr, torch.int64), t(ids, torch.int32)).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    # the two-phase (sharded) form over 3 column shards gives the same ranks
+    cuts = [0, N // 3, 2 * N // 3, N]
+    parts = [buf[:, cuts[k]:cuts[k + 1]] for k in range(3) if cuts[k + 1] > cuts[k]]
+    offs = [cuts[k] for k in range(3) if cuts[k + 1] > cuts[k]]
+    rp, gp, idt, fp, fc = t(row_ptr, torch.int64), t(grp_ptr, torch.int64), t(ids, torch.int32), t(filt_ptr, torch.int64), t(filt_col or [0], torch.int32)
+    true = torch.stack([hp.group_true_scores(p, o, rp, gp, idt) for p, o in zip(parts, offs)]).max(0).values
+    counts = sum(hp.rank_counts(p, o, fp, fc, rp, true) for p, o in zip(parts, offs))
+    np.testing.assert_array_equal((counts[:, 0] + counts[:, 1] // 2).cpu().numpy(), ref)
