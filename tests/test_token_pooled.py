@@ -122,3 +122,62 @@ def test_token_pooled_training_trajectory_vs_oracle(okge_lib):
     close = np.isclose(e.W.cpu().numpy(), We, rtol=2e-3, atol=2e-4)
     assert close.mean() > 0.95 and np.abs(e.W.cpu().numpy() - We).max() < 0.3        # at most lr per step
     np.testing.assert_allclose(e.running_mean.cpu().numpy(), bn_e["running_mean"], rtol=0, atol=0.1)     # follows W
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_random_token_pooled_step_vs_oracle(okge_lib, i):
+    """random shapes (slot size, token-sequence length incl. the hot-token LDS path and rare tokens, repeated ids,
+    one-sided batches) through TokenPooledTrainStep.forward_backward against the oracle"""
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch, positives_from_dense
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    rng = np.random.default_rng(4200 + i)
+    d = int(rng.choice([8, 24, 64, 100, 256]))
+    L = int(rng.choice([1, 3, 10, 17]))
+    n_ent, n_rel, vt_e, vt_r = int(rng.integers(30, 400)), int(rng.integers(4, 25)), int(rng.integers(6, 300)), int(rng.integers(6, 60))
+    pool = str(rng.choice(["sum", "mean", "max"]))
+    bn = bool(rng.random() < 0.6)
+    n_po, n_sp = int(rng.integers(0, 70)), int(rng.integers(0, 70))
+    if n_po + n_sp == 0:
+        n_sp = 7
+
+    def tokens(n, vocab):
+        m = np.zeros((n, L), np.int32)
+        for r in range(n):
+            k = int(rng.integers(1, L + 1))
+            m[r, :k] = rng.integers(1, vocab, k)                       # ids < 32 take the LDS path, repeats allowed
+        return m
+    ent_tok, rel_tok = tokens(n_ent, vt_e), tokens(n_rel, vt_r)
+    We = (rng.standard_normal((vt_e, d)) * 0.3).astype(np.float32)
+    Wr = (rng.standard_normal((vt_r, d)) * 0.3).astype(np.float32)
+    N = int(rng.integers(1, 300))
+    cand = rng.integers(2, n_ent, N).astype(np.int32)                   # repeats allowed
+    po = (rng.integers(2, n_rel, n_po).astype(np.int32), rng.integers(2, n_ent, n_po).astype(np.int32)) if n_po else None
+    sp = (rng.integers(2, n_ent, n_sp).astype(np.int32), rng.integers(2, n_rel, n_sp).astype(np.int32)) if n_sp else None
+    B = n_po + n_sp
+    y = np.zeros((B, N), np.float32)
+    for b in range(B):
+        y[b, rng.choice(N, size=int(rng.integers(0, min(3, N) + 1)), replace=False)] = 1
+    mk_bn = lambda: dict(weight=rng.random(d).astype(np.float32), bias=(rng.standard_normal(d) * 0.1).astype(np.float32),   # noqa: E731
+                         running_mean=np.zeros(d, np.float32), running_var=np.ones(d, np.float32))
+    bn_e, bn_r = (mk_bn(), mk_bn()) if bn else (None, None)
+    if bn and min(N, n_po or N, n_sp or N) < 2:
+        pytest.skip("batch-norm over a single row divides by zero variance in both implementations")
+    e = TokenSlot(dev(We), dev(ent_tok), pool, bn, dev(bn_e["weight"]) if bn else None, dev(bn_e["bias"]) if bn else None)
+    r = TokenSlot(dev(Wr), dev(rel_tok), pool, bn, dev(bn_r["weight"]) if bn else None, dev(bn_r["bias"]) if bn else None)
+    ref = ko.unigram_step_forward_backward(ko.COMPLEX if d % 2 == 0 else ko.DISTMULT, We, Wr, ent_tok, rel_tok, po, sp, cand, y,
+                                           pool=pool, bn_ent=bn_e, bn_rel=bn_r)
+    st = TokenPooledTrainStep(e, r, "complex" if d % 2 == 0 else "distmult")
+    b = PrefixBatch(cand_ids=dev(cand))
+    if po:
+        b.po_rel, b.po_obj = dev(po[0]), dev(po[1])
+    if sp:
+        b.sp_subj, b.sp_rel = dev(sp[0]), dev(sp[1])
+    b.pos_row, b.pos_col = positives_from_dense(dev(y))
+    loss = float(st.forward_backward(b)[0])
+    info = dict(i=i, d=d, L=L, pool=pool, bn=bn, n_po=n_po, n_sp=n_sp, N=N)
+    assert abs(loss - ref["loss"]) <= 1e-4 * abs(ref["loss"]) + 1e-5, (info, loss, ref["loss"])
+    for mine, want in ((e.dW, ref["dWe"]), (r.dW, ref["dWr"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), want, rtol=0, atol=2e-4 * np.abs(want).max() + 1e-7, err_msg=str(info))
+    if bn:
+        np.testing.assert_allclose(e.d_bn[:d].cpu().numpy(), ref["d_bn_ent"][0], rtol=0, atol=2e-4 * np.abs(ref["d_bn_ent"][0]).max() + 1e-7)
+        np.testing.assert_allclose(e.running_var.cpu().numpy(), bn_e["running_var"], rtol=1e-4, atol=1e-6)
