@@ -310,6 +310,26 @@ int okge_collate_batch(const okge_prefix_table *table, const int64_t *rows, int3
                        int32_t use_batch_shared_entities, int32_t min_size_batch_labels, uint64_t seed,
                        okge_collated *out);
 
+/* n_batches batches of B prefixes each (rows = n_batches * B indices, batch k = rows[k*B .. (k+1)*B)) in one call; all
+ * arrays of all batches are laid out in ONE caller-allocated int32 arena (pin it: the whole group crosses PCIe in one
+ * copy) and layout[k] says where batch k's arrays start (int32 element offsets; the three int64 arrays sit on even
+ * offsets) and how long they are.  arena_used returns the elements used, or -- with OKGE_ERR_WORKSPACE -- the elements
+ * needed so far.  Sufficient capacity: sum over all rows of 6 * (this_end - this_start) + (all_end - all_start) + 10,
+ * plus n_batches * (candidate capacity + 64).  Same per-batch semantics as okge_collate_batch (batch k uses a seed derived
+ * from `seed` and k). */
+typedef struct okge_arena_batch {
+    int64_t off_po_rel, off_po_obj, off_sp_subj, off_sp_rel, off_pos_row, off_pos_col, off_cand;
+    int64_t off_row_ptr, off_grp_ptr, off_ids, off_filt_ptr, off_filt_col;
+    int64_t nnz, n_cand, n_groups, n_ids, n_filter;
+    int32_t n_po, n_sp;
+    double normalizer_loss, normalizer_metric;
+} okge_arena_batch;
+
+int okge_collate_batches(const okge_prefix_table *table, const int64_t *rows, int32_t n_batches, int32_t B,
+                         int32_t is_training, int32_t use_batch_shared_entities, int32_t min_size_batch_labels,
+                         uint64_t seed, int32_t *arena, int64_t arena_cap, okge_arena_batch *layout,
+                         int64_t *arena_used);
+
 /* ---- dataset loader (HOST; text files -> the tensors okge_collate_batch reads) --------------------------
  * Replaces OneToNMentionRelationDataset._collect_seen_triples / merge_all_splits_triples / create_data_tensors
  * (dataset.py:480-710) for the 5-column id format  s \t p \t o \t subj-mention-ids \t obj-mention-ids

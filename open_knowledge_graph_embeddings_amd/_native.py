@@ -30,7 +30,7 @@ EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_t
            "okge_train_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
            "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
-           "okge_collate_batch", "okge_dataset_open", "okge_dataset_sizes",
+           "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
            "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
@@ -87,6 +87,13 @@ class Collated(Structure):
                 ("grp_ptr", c_void_p), ("ids", c_void_p), ("filt_ptr", c_void_p), ("filt_col", c_void_p),
                 ("n_po", c_int32), ("n_sp", c_int32), ("nnz", c_int64), ("n_cand", c_int64), ("n_groups", c_int64),
                 ("n_ids", c_int64), ("n_filter", c_int64), ("normalizer_loss", c_double), ("normalizer_metric", c_double)]
+
+
+class ArenaBatch(Structure):
+    _fields_ = [(k, c_int64) for k in ("off_po_rel", "off_po_obj", "off_sp_subj", "off_sp_rel", "off_pos_row", "off_pos_col",
+                                       "off_cand", "off_row_ptr", "off_grp_ptr", "off_ids", "off_filt_ptr", "off_filt_col",
+                                       "nnz", "n_cand", "n_groups", "n_ids", "n_filter")] + \
+               [("n_po", c_int32), ("n_sp", c_int32), ("normalizer_loss", c_double), ("normalizer_metric", c_double)]
 
 
 def needs_build():
@@ -173,6 +180,9 @@ def lib():
     L.okge_collate_batch.restype = c_int32
     L.okge_collate_batch.argtypes = [POINTER(PrefixTable), c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint64,
                                      POINTER(Collated)]
+    L.okge_collate_batches.restype = c_int32
+    L.okge_collate_batches.argtypes = [POINTER(PrefixTable), c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint64,
+                                       c_void_p, c_int64, POINTER(ArenaBatch), POINTER(c_int64)]
     L.okge_dataset_open.restype = c_int32
     L.okge_dataset_open.argtypes = [c_char_p, c_char_p, c_char_p, c_int32, POINTER(c_void_p)]
     L.okge_dataset_sizes.restype = c_int32

@@ -75,7 +75,8 @@ class OneToNBatchProducer:
 
     def __init__(self, seen_prefixes_tensor, seen_entities_tensor, all_splits_entities_tensor, entity_vocab_size,
                  entity_special_vocab_size=2, batch_size=512, is_training_data=True, use_batch_shared_entities=False,
-                 min_size_batch_labels=-1, device="cpu", shuffle=False, drop_last=True, seed=0, prefetch=2):
+                 min_size_batch_labels=-1, device="cpu", shuffle=False, drop_last=True, seed=0, prefetch=2,
+                 batches_per_call=16):
         i32 = lambda x: np.ascontiguousarray(np.asarray(x.cpu() if isinstance(x, torch.Tensor) else x, dtype=np.int32))  # noqa: E731
         self.prefixes = i32(seen_prefixes_tensor).reshape(-1, 7)
         self.seen = i32(seen_entities_tensor).reshape(-1)
@@ -85,6 +86,7 @@ class OneToNBatchProducer:
         self.shared, self.min_size = bool(use_batch_shared_entities), int(min_size_batch_labels or 0)
         self.device = torch.device(device)
         self.shuffle, self.drop_last, self.seed, self.prefetch = shuffle, drop_last, int(seed), max(1, int(prefetch))
+        self.batches_per_call = max(1, int(batches_per_call))
         self.epoch = 0
         self._lib = N.lib()
         t = N.PrefixTable()
@@ -167,15 +169,66 @@ class OneToNBatchProducer:
         stop = n - n % self.batch_size if self.drop_last else n
         return [order[i:i + self.batch_size] for i in range(0, stop, self.batch_size)]
 
+    # -- several batches per library call: one arena, one H2D copy, little interpreter time per step ---------------
+    def collate_group_host(self, rows_list, seed=0):
+        """equal-sized batches -> (pinned arena, ctypes layout array); okge_collate_batches runs without the GIL"""
+        K, B = len(rows_list), int(rows_list[0].shape[0])
+        rows = np.ascontiguousarray(np.concatenate(rows_list), dtype=np.int64)
+        if rows.min() < 0 or rows.max() >= self.prefixes.shape[0]:
+            raise N.OkgeError("collate: prefix row outside the table")
+        # per batch the library carves 8B + 5*len_this + len_all + cand capacity (+ alignment) int32 elements
+        len_this, len_all = int(self._len_this[rows].sum()), 0 if self.training else int(self._len_all[rows].sum())
+        cap = 6 * len_this + len_all + 10 * int(rows.shape[0]) + 64 * K
+        if self.shared:
+            cap += K * max(self.min_size, 0) + (len_this if self.training else len_all)
+        arena = torch.empty(cap, dtype=torch.int32, pin_memory=self.device.type == "cuda")
+        layout = (N.ArenaBatch * K)()
+        used = ctypes.c_int64()
+        N.check(self._lib.okge_collate_batches(ctypes.byref(self._table), rows.ctypes.data, K, B, int(self.training),
+                                               int(self.shared), self.min_size, ctypes.c_uint64(seed), arena.data_ptr(), cap,
+                                               layout, ctypes.byref(used)), "okge_collate_batches")
+        return arena[:used.value], layout
+
+    def group_to_device(self, arena, layout):
+        """one copy for the whole group, then views"""
+        dev = arena.to(self.device, non_blocking=True) if self.device.type == "cuda" else arena
+        out = []
+        for L in layout:
+            i32 = lambda o, n: dev[o:o + n]                                   # noqa: E731
+            i64 = lambda o, n: dev[o:o + 2 * n].view(torch.int64)             # noqa: E731
+            n_po, n_sp = L.n_po, L.n_sp
+            pb = PrefixBatch(po_rel=i32(L.off_po_rel, n_po) if n_po else None, po_obj=i32(L.off_po_obj, n_po) if n_po else None,
+                             sp_subj=i32(L.off_sp_subj, n_sp) if n_sp else None, sp_rel=i32(L.off_sp_rel, n_sp) if n_sp else None,
+                             pos_row=i32(L.off_pos_row, L.nnz), pos_col=i32(L.off_pos_col, L.nnz),
+                             cand_ids=i32(L.off_cand, L.n_cand) if self.shared else None, cand_unique=True,
+                             cand_first=self.offset, n_cand=int(L.n_cand))
+            cb = CollatedBatch(pb, L.normalizer_loss, L.normalizer_metric, int(L.n_cand))
+            if not self.training:
+                B = n_po + n_sp
+                cb.row_ptr, cb.grp_ptr = i64(L.off_row_ptr, B + 1), i64(L.off_grp_ptr, L.n_groups + 1)
+                cb.ids, cb.filt_ptr, cb.filt_col = i32(L.off_ids, L.n_ids), i64(L.off_filt_ptr, B + 1), i32(L.off_filt_col, L.n_filter)
+            out.append(cb)
+        return out
+
     def __iter__(self):
         plan = self.batch_rows()
         self.epoch += 1
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        K = self.batches_per_call
+        # full-size batches go K at a time; a shorter last batch (drop_last=False) goes alone
+        groups, cur = [], []
+        for rows in plan:
+            if cur and (len(cur) == K or rows.shape[0] != cur[0].shape[0]):
+                groups.append(cur)
+                cur = []
+            cur.append(rows)
+        if cur:
+            groups.append(cur)
 
         def work():
             try:
-                for i, rows in enumerate(plan):
-                    q.put(self.collate_host(rows, seed=((self.seed << 20) ^ (self.epoch << 40) ^ i) & (2 ** 64 - 1)))
+                for i, g in enumerate(groups):
+                    q.put(self.collate_group_host(g, seed=((self.seed << 20) ^ (self.epoch << 40) ^ i) & (2 ** 64 - 1)))
                 q.put(None)
             except BaseException as e:          # surfaced in the consumer
                 q.put(e)
@@ -188,7 +241,7 @@ class OneToNBatchProducer:
                 break
             if isinstance(item, BaseException):
                 raise item
-            yield self.to_device(*item)
+            yield from self.group_to_device(*item)
         th.join()
 
 

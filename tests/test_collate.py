@@ -313,3 +313,25 @@ def test_toy_kg_end_to_end_training_improves_mrr(okge_lib):
     res, n_groups = PipelinedEvaluator(E, R, "complex", engine=hp).run(valid)
     assert abs(res["mrr"].avg - after) < 1e-6 and n_groups == res["mrr"].count > 0
     assert 0.0 <= res["h1"].avg <= res["h3"].avg <= res["h10"].avg <= res["h50"].avg <= 1.0 and res["mr"].avg >= 0
+
+
+@pytest.mark.parametrize("shared,training", [(False, True), (False, False), (True, True), (True, False)])
+def test_grouped_collate_equals_single_batches(okge_lib, shared, training):
+    """okge_collate_batches (K batches, one arena) == K calls of okge_collate_batch, array by array"""
+    rng = np.random.default_rng(31 + 2 * shared + training)
+    z = random_tables(rng, 3000, 400)
+    p = producer(z, training, shared, 0, batch_size=32)
+    rows_list = [rng.choice(400, size=32, replace=False) for _ in range(5)]
+    group = p.group_to_device(*p.collate_group_host(rows_list, seed=9))
+    assert len(group) == 5
+    for rows, g in zip(rows_list, group):
+        one = p.collate(rows)
+        for name in ("po_rel", "po_obj", "sp_subj", "sp_rel", "pos_row", "pos_col", "cand_ids"):
+            a, b2 = getattr(g.batch, name), getattr(one.batch, name)
+            assert (a is None) == (b2 is None)
+            if a is not None:
+                np.testing.assert_array_equal(a.numpy(), b2.numpy(), err_msg=name)
+        assert (g.normalizer_loss, g.normalizer_metric, g.n_cand) == (one.normalizer_loss, one.normalizer_metric, one.n_cand)
+        if not training:
+            for name in ("row_ptr", "grp_ptr", "ids", "filt_ptr", "filt_col"):
+                np.testing.assert_array_equal(getattr(g, name).numpy(), getattr(one, name).numpy(), err_msg=name)
