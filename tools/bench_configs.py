@@ -50,6 +50,54 @@ def run(name, step, batches, steps=30, warmup=5):
     return out
 
 
+def rank_shape(world, dev, t):
+    """what ONE of `world` ranks computes per step of `bench.py --gpus world` (weak scaling: global batch world x 512 rows
+    against this rank's share of the FB15k-237-shaped candidates); the two all-reduces are not part of this timing"""
+    from open_knowledge_graph_embeddings_amd import synthetic
+    from open_knowledge_graph_embeddings_amd.sharded import shard_range
+    import dataclasses
+    w = synthetic.WORKLOADS["S-FB"]
+    rank = world // 2
+    wg = dataclasses.replace(w, n_po=w.n_po * world, n_sp=w.n_sp * world)
+    E, R = synthetic.make_tables(w, seed=1234)
+    lo, hi = shard_range(w.n_ent, world, rank)
+    Et, Rt = t(E[lo:hi].copy()), t(R)
+    eng = H.HotPath(dev)
+    hb = synthetic.make_batch(wg, seed=5)
+    batch = H.PrefixBatch(po_rel=t(hb["po_rel"]), po_obj=t(hb["po_obj"]), sp_subj=t(hb["sp_subj"]), sp_rel=t(hb["sp_rel"]),
+                          pos_row=t(hb["pos_row"]), pos_col=t(hb["pos_col"]), cand_first=2, n_cand=w.N)
+    shard = H.Shard(lo, hi, lo - 2)
+    local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
+                          pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=hi - lo)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    sE, sR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def one():
+        qe = eng.encode_queries(Et, Rt, w.scorer, batch, shard)
+        dq = torch.empty_like(qe[0])
+        eng.train_tiles(Et, Rt, w.scorer, qe[0], local, shard, dE, dq, w.N, normalizer=float(wg.B) * w.N, loss_out=loss,
+                        grads_zero=True)
+        eng.prefix_backward(Et, Rt, w.scorer, batch, shard, dq, qe[1], dE, dR)
+        eng.adagrad2(Et, dE, sE, Rt, dR, sR, w.lr)
+    for _ in range(5):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        one()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / 50
+    eng.timing(True)
+    for _ in range(10):
+        one()
+    torch.cuda.synchronize()
+    per = {k: round(v[0] / v[1] * 1e3, 2) for k, v in eng.timing_collect().items()}
+    eng.timing(False)
+    print(json.dumps({"workload": f"S-FB-rank{world} (one rank's compute, no exchange)", "ms_per_step": round(ms, 4), "kernels_us": per}), flush=True)
+
+
+
 def main():
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(1)
@@ -83,51 +131,9 @@ def main():
         flops = 6.0 * B * (n_ent - 2) * d
         print(json.dumps({"S-OLP-shard step TFLOP/s (6BNd)": round(flops / out["ms_per_step"] / 1e9, 1)}), flush=True)
         del step, batches, E, R
-    if "S-FB-rank8" in which:
-        # what ONE of 8 ranks computes per step of `bench.py --gpus 8` (weak scaling: global batch 8 x 512 rows against
-        # this rank's 1/8 of the FB15k-237-shaped candidates); the two all-reduces are not part of this timing
-        from open_knowledge_graph_embeddings_amd import synthetic
-        from open_knowledge_graph_embeddings_amd.sharded import shard_range
-        import dataclasses
-        w = synthetic.WORKLOADS["S-FB"]
-        world, rank = 8, 3
-        wg = dataclasses.replace(w, n_po=w.n_po * world, n_sp=w.n_sp * world)
-        E, R = synthetic.make_tables(w, seed=1234)
-        lo, hi = shard_range(w.n_ent, world, rank)
-        Et, Rt = t(E[lo:hi].copy()), t(R)
-        eng = H.HotPath(dev)
-        hb = synthetic.make_batch(wg, seed=5)
-        batch = H.PrefixBatch(po_rel=t(hb["po_rel"]), po_obj=t(hb["po_obj"]), sp_subj=t(hb["sp_subj"]), sp_rel=t(hb["sp_rel"]),
-                              pos_row=t(hb["pos_row"]), pos_col=t(hb["pos_col"]), cand_first=2, n_cand=w.N)
-        shard = H.Shard(lo, hi, lo - 2)
-        local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
-                              pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=hi - lo)
-        dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
-        sE, sR = torch.zeros_like(Et), torch.zeros_like(Rt)
-        loss = torch.zeros(1, dtype=torch.float64, device=dev)
-
-        def one():
-            qe = eng.encode_queries(Et, Rt, w.scorer, batch, shard)
-            dq = torch.empty_like(qe[0])
-            eng.train_tiles(Et, Rt, w.scorer, qe[0], local, shard, dE, dq, w.N, normalizer=float(wg.B) * w.N, loss_out=loss,
-                            grads_zero=True)
-            eng.prefix_backward(Et, Rt, w.scorer, batch, shard, dq, qe[1], dE, dR)
-            eng.adagrad2(Et, dE, sE, Rt, dR, sR, w.lr)
-        for _ in range(5):
-            one()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(50):
-            one()
-        torch.cuda.synchronize()
-        ms = 1e3 * (time.perf_counter() - t0) / 50
-        eng.timing(True)
-        for _ in range(10):
-            one()
-        torch.cuda.synchronize()
-        per = {k: round(v[0] / v[1] * 1e3, 2) for k, v in eng.timing_collect().items()}
-        eng.timing(False)
-        print(json.dumps({"workload": "S-FB-rank8 (one rank's compute, no exchange)", "ms_per_step": round(ms, 4), "kernels_us": per}), flush=True)
+    for world in (2, 4, 8):
+        if f"S-FB-rank{world}" in which:
+            rank_shape(world, dev, t)
     if "S-OLP-tok" in which:
         from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
         n_ent, n_rel, d, B, N, L, vt_e, vt_r = 2_500_000, 100_000, 256, 4096, 8192, 10, 200_000, 50_000
