@@ -369,20 +369,29 @@ __global__ __launch_bounds__(256) void kl_count_pos_kernel(const int32_t *__rest
     if (i < nnz && pos_row[i] >= 0) atomicAdd(row_ysum + pos_row[i], 1.0f);      // row < 0: padding (fixed-size graphs)
 }
 
+// row log-sum-exp from the per-(tile, row) (max, sum-exp) pairs of the stats pass: one wave per batch row, lanes stride
+// over the tiles (a thread per row walked 2 x tiles strided loads in sequence: 98 us at 228 tiles)
 __global__ __launch_bounds__(256) void kl_row_lse_kernel(const float *__restrict__ stats, int tiles, int B, int Bpad,
                                                          float *__restrict__ row_lse)
 {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const float2 *st = reinterpret_cast<const float2 *>(stats);
-    float M = -INFINITY;
-    for (int t = 0; t < tiles; ++t) M = fmaxf(M, st[(size_t)t * Bpad + b].x);
-    float S = 0.f;
-    for (int t = 0; t < tiles; ++t) {
+    float M = -INFINITY, S = 0.f;                    // running (max, sum of exp(x - max)) of this lane's tiles
+    for (int t = lane; t < tiles; t += 64) {
         const float2 v = st[(size_t)t * Bpad + b];
-        S += v.y * expf(v.x - M);
+        const float m2 = fmaxf(M, v.x);
+        if (m2 > -INFINITY) S = S * expf(M - m2) + v.y * expf(v.x - m2);
+        M = m2;
     }
-    row_lse[b] = M + logf(S);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float Mo = __shfl_xor(M, o), So = __shfl_xor(S, o);
+        const float m2 = fmaxf(M, Mo);
+        if (m2 > -INFINITY) S = S * expf(M - m2) + So * expf(Mo - m2);
+        M = m2;
+    }
+    if (lane == 0) row_lse[b] = M + logf(S);
 }
 
 __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, float *__restrict__ g,
@@ -798,7 +807,7 @@ hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, c
     if (e != hipSuccess) return e;
     if (nnz > 0) hipLaunchKernelGGL(kl_count_pos_kernel, dim3((nnz + 255) / 256), dim3(256), 0, st, pos_row, nnz, row_ysum);
     if (tiles > 0)
-        hipLaunchKernelGGL(kl_row_lse_kernel, dim3((B + 255) / 256), dim3(256), 0, st, stats, tiles, B, Bpad, row_lse);
+        hipLaunchKernelGGL(kl_row_lse_kernel, dim3((B + 3) / 4), dim3(256), 0, st, stats, tiles, B, Bpad, row_lse);
     return hipGetLastError();
 }
 

@@ -103,6 +103,19 @@ def main():
     rng = np.random.default_rng(1)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
     which = sys.argv[1:] or ["S-DM", "S-OLP-shard", "S-OLP-tok"]
+    if "S-FB-kl" in which:
+        # configs[1] with the softmax / KL loss (trainer.py:99-101): one extra score pass for the row log-sum-exp
+        from open_knowledge_graph_embeddings_amd import synthetic
+        w = synthetic.WORKLOADS["S-FB"]
+        E, R = synthetic.make_tables(w, seed=1234)
+        step = FusedTrainStep(t(E), t(R), w.scorer, loss="kl", lr=w.lr, input_dropout=w.input_dropout, seed=1)
+        batches = []
+        for i in range(4):
+            hb = synthetic.make_batch(w, seed=1234 + i)
+            batches.append(H.PrefixBatch(po_rel=t(hb["po_rel"]), po_obj=t(hb["po_obj"]), sp_subj=t(hb["sp_subj"]), sp_rel=t(hb["sp_rel"]),
+                                         pos_row=t(hb["pos_row"]), pos_col=t(hb["pos_col"]), cand_first=2, n_cand=w.N))
+        run("S-FB-kl", step, batches, steps=100, warmup=10)
+        del step, batches
     if "S-DM" in which:
         n_ent, n_rel, d, B, N = 14543, 239, 512, 512, 10000
         E, R = (rng.standard_normal((n, d), dtype=np.float32) * 0.1 for n in (n_ent, n_rel))
