@@ -132,6 +132,12 @@ class TokenPooledTrainStep:
         self.device = entity.W.device
         self.engine = engine or H.HotPath(self.device)
         self.pool = PoolEngine(self.device)
+        # the relation slot's encode / backward calls run on a side stream next to the entity slot's: five chains of
+        # small latency-bound kernels per step, two independent slots (own workspace: the calls overlap).  Off under
+        # graph capture (GraphedTrainStep), where one stream keeps the capture simple.
+        self.pool_side = PoolEngine(self.device)
+        self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.overlap_slots = self.side is not None
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.step_dev = None              # device step counter, attached by GraphedTrainStep
         self._rows = 0
@@ -176,8 +182,26 @@ class TokenPooledTrainStep:
                  (ent, _i32(batch.po_obj, dev), 0, n_po, EX[N_c:N_c + n_po], EV[N_c:N_c + n_po], dEV[N_c:N_c + n_po], sv[2] if bn_e else None),
                  (ent, _i32(batch.sp_subj, dev), 0, n_sp, EX[N_c + n_po:N_c + B], EV[N_c + n_po:N_c + B], dEV[N_c + n_po:N_c + B], sv[3] if bn_e else None),
                  (rel, _i32(batch.sp_rel, dev), 0, n_sp, RX[n_po:B], RV[n_po:B], dRV[n_po:B], sv[4] if bn_r else None)]
-        for slot, ids, first, n, raw, out, _, saved in calls:
-            pe.encode(slot, ids, first, n, True, raw, out if slot.bn is not None else raw, saved)
+        two = self.overlap_slots and not torch.cuda.is_current_stream_capturing()
+        main = torch.cuda.current_stream(dev) if two else None
+
+        def on_slots(fn):
+            """fn(engine, call) for the five calls: entity slot on the current stream, relation slot on the side stream"""
+            if not two:
+                for call in calls:
+                    fn(pe, call)
+                return
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                for call in calls:
+                    if call[0] is rel:
+                        fn(self.pool_side, call)
+            for call in calls:
+                if call[0] is ent:
+                    fn(pe, call)
+            main.wait_stream(self.side)
+
+        on_slots(lambda eng_, c_: eng_.encode(c_[0], c_[1], c_[2], c_[3], True, c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]))
         EVt, RVt = (EV if bn_e else EX), (RV if bn_r else RX)
         # the fused step on the virtual tables: candidates are rows 0..N-1, prefix entities follow
         ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
@@ -191,8 +215,7 @@ class TokenPooledTrainStep:
         self.engine.forward_backward(EVt[:N_c + B], RVt[:B], self.scorer, vb, dEV[:N_c + B], dRV[:B], loss=self.loss,
                                      label_smoothing=self.label_smoothing, normalizer=normalizer, loss_out=self.loss_out,
                                      scores=scores, grads_zero=True)
-        for slot, ids, first, n, raw, _, d_out, saved in calls:
-            pe.backward(slot, ids, first, n, raw, d_out, saved)
+        on_slots(lambda eng_, c_: eng_.backward(c_[0], c_[1], c_[2], c_[3], c_[4], c_[6], c_[7]))
         dEV[:N_c + B].zero_()
         dRV[:B].zero_()
         return self.loss_out
