@@ -124,13 +124,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    dev = torch.device("cuda", local_rank)
+    # OKGE_BENCH_ONE_GPU=1: rehearsal of the multi-rank control flow on a one-GPU box -- every rank on cuda:0, gloo
+    # instead of RCCL (which refuses two ranks per device).  Not a measurement.
+    one_gpu = os.environ.get("OKGE_BENCH_ONE_GPU") == "1"
+    dev = torch.device("cuda", 0 if one_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import dataclasses
     w = synthetic.WORKLOADS[args.workload]
@@ -192,13 +198,15 @@ def main():
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, separate pass ------------------
     roof = None
+    # (every rank runs these steps -- the sharded step contains collectives -- but only rank 0 times its kernels)
+    eng = step.engine
     if rank == 0:
-        eng = step.engine
         eng.timing(True)
-        ksteps = min(args.steps, 50)
-        for i in range(ksteps):
-            step.step(batches[i % N_BATCHES])
-        torch.cuda.synchronize()
+    ksteps = min(args.steps, 50)
+    for i in range(ksteps):
+        step.step(batches[i % N_BATCHES])
+    barrier()
+    if rank == 0:
         per_kernel = eng.timing_collect()
         eng.timing(False)
         tot_ms, cnt = per_kernel["fused_tile_train"]
