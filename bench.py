@@ -259,10 +259,11 @@ def main():
     if not args.no_cpu_baseline and world == 1 and not sharded:
         cpu = cpu_baseline(w, host_batches)
     line = {
-        "metric": "training triples/sec (1-vs-all ComplEx d=200)", "value": triples / elapsed, "unit": "triples/s",
+        "metric": "training triples/sec (1-vs-all ComplEx d=200)" if w.name.startswith("S-FB") and w.d == 200
+                  else f"training triples/sec (1-vs-all {w.scorer} d={w.d})", "value": triples / elapsed, "unit": "triples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{w.name}: FB15k-237-shaped |E|={w.n_ent} |R|={w.n_rel} d={w.d} ComplEx 1-vs-all "
+        "config": {"workload": f"{w.name}: {'FB15k-237' if w.name.startswith('S-FB') else 'OLPBENCH'}-shaped |E|={w.n_ent} |R|={w.n_rel} d={w.d} ComplEx 1-vs-all "
                                f"N={w.N}, B={w_run.B} ({w_run.n_po} po + {w_run.n_sp} sp), BCE, input_dropout "
                                f"{w.input_dropout}, dense Adagrad lr {w.lr}",
                    "global_batch": w_run.B,
