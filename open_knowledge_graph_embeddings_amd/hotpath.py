@@ -10,6 +10,7 @@ Reference call sites this module stands in for (paths relative to the reference 
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -41,6 +42,33 @@ class DropoutSpec:
 
 
 NO_DROP = DropoutSpec()
+
+# OKGE_VALIDATE=1: check every id tensor against the table sizes before a call (one host sync per call).  The kernels
+# trust their ids -- they live in device memory -- so a bad id is an out-of-bounds access; use this while integrating.
+VALIDATE = os.environ.get("OKGE_VALIDATE") == "1"
+
+
+def validate_ids(batch, n_ent, n_rel):
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return                                     # no host reads inside a graph capture
+    def check(name, x, hi):
+        if x is not None and x.numel():
+            lo_, hi_ = int(x.min()), int(x.max())
+            if lo_ < 0 or hi_ >= hi:
+                raise N.OkgeError(f"{name}: ids span [{lo_}, {hi_}] but the table has {hi} rows")
+    check("po_rel", batch.po_rel, n_rel)
+    check("sp_rel", batch.sp_rel, n_rel)
+    check("po_obj", batch.po_obj, n_ent)
+    check("sp_subj", batch.sp_subj, n_ent)
+    if batch.cand_table is None:
+        check("cand_ids", batch.cand_ids, n_ent)
+        if batch.cand_ids is None and (batch.cand_first < 0 or batch.cand_first + batch.n_cand > n_ent):
+            raise N.OkgeError("candidate range outside the entity table")
+    n_c = batch.n_candidates if batch.cand_table is None else batch.cand_table.shape[0]
+    if batch.pos_row is not None and batch.pos_row.numel():
+        live = batch.pos_row >= 0                  # (row -1, col INT32_MAX) pads a fixed-capacity list (GraphedTrainStep)
+        check("pos_col", batch.pos_col[live], n_c)
+        check("pos_row", batch.pos_row[live], batch.B)
 
 # Philox stream ids: one per place the reference draws an independent Bernoulli mask
 STREAM_CAND, STREAM_PO_ENT, STREAM_PO_REL, STREAM_SP_ENT, STREAM_SP_REL = 0, 1, 2, 3, 4
@@ -140,6 +168,10 @@ class HotPath:
             self._ws_bytes = need
         return self._ws
 
+    def _check(self, batch, E, R):
+        if VALIDATE:
+            validate_ids(batch, E.shape[0], R.shape[0])
+
     def _tables(self, E, R, scorer):
         for t in (E, R):
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
@@ -175,6 +207,7 @@ class HotPath:
     # -- entry points -------------------------------------------------------------------------------
     def score(self, E, R, scorer, batch: PrefixBatch, out=None):
         """(B, N) scores of every prefix against every candidate (eval / *_prefix_score)."""
+        self._check(batch, E, R)
         pb, c, keep = self._batch(batch)
         t = self._tables(E, R, scorer)
         B, n = batch.B, c.n
@@ -192,6 +225,7 @@ class HotPath:
                          normalizer=None, loss_out=None, scores=None, grads_zero=False, loss_only=False):
         """Fused forward + loss + backward; accumulates into dE / dR; returns the summed loss as a
         device double[1] tensor (no host sync)."""
+        self._check(batch, E, R)
         pb, c, keep = self._batch(batch)
         t = self._tables(E, R, scorer)
         B, n = batch.B, c.n

@@ -69,6 +69,8 @@ class FusedTrainStep:
 
     def _fast_forward_backward(self, batch: H.PrefixBatch, normalizer):
         """same call as HotPath.forward_backward for int32 device tensors (what the batch producer emits)"""
+        if H.VALIDATE:
+            H.validate_ids(batch, self.E.shape[0], self.R.shape[0])
         t, pb, c, pos, drops = self._descriptors()
         sd = self.step_dev.data_ptr() if self.step_dev is not None else None
         for d_ in drops:

@@ -9,6 +9,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("OKGE_VALIDATE", "1")      # tests check id ranges before every kernel call (a bad id is an OOB access)
 
 
 def pytest_configure(config):
