@@ -196,9 +196,15 @@ int okge_row_logsumexp(const okge_tables *t, const okge_shard *shard, const floa
 int okge_prefix_backward(const okge_tables *t, const okge_shard *shard, const okge_prefix_batch *batch,
                          const float *dQ, int64_t ldq, const float *ent_rows, float *dE, float *dR, void *stream);
 
-/* Bytes of scratch okge_train_forward_backward / okge_score_prefixes need for a batch of B rows
- * against N candidates with slot size d (0 on invalid arguments). */
+/* Bytes of scratch okge_train_forward_backward / okge_train_tiles need for a batch of B rows against N candidates with
+ * slot size d (0 on invalid arguments).  Training sweeps the candidates in ranges (default: G^T of one range <= 1 GiB,
+ * environment OKGE_GT_MBYTES), so this grows with B x min(N, range), not with B x N: the reference's autograd graph
+ * keeps several (B, N) fp32 tensors alive instead (trainer.py:75-106). */
 size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d);
+/* Scratch of the scoring-only calls (okge_score_prefixes, okge_evaluate_batch): the folded query block. */
+size_t okge_score_workspace_bytes(int32_t B, int32_t d);
+/* Scratch of okge_row_logsumexp: query block + one range of (max, sum-exp) tile statistics. */
+size_t okge_lse_workspace_bytes(int32_t B, int32_t N, int32_t d);
 
 /* ---- embedder --------------------------------------------------------------------------------------
  * Replaces LookupBaseRelationEmbedder._encode for the lookup embedder with batch-norm / projection /

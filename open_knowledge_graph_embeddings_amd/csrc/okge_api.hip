@@ -115,7 +115,12 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Geometry {
     int    B, N, d, Bpad, D16, KB, LDK, ldq, ldg, tiles, b_split, b_per_block, nsplit;
     int    tile_w, ktiles;      // fused train kernel: tile width (32 or 64 candidates) and tile count
-    size_t off_Q, off_tptr, off_GT, off_Cm, off_slab, off_loss, off_stats, off_lse, off_ysum, off_dcs, total;
+    // training sweeps the candidates in RANGES of range_n (a multiple of 64) so that the one (B, N)-shaped
+    // intermediate, G^T, and everything sized like it (masked rows Cm, KL statistics) is O(B x range_n):
+    // 41 GB -> 1 GB at |E| = 2.5 M, B = 4096.  A range is one tile-kernel launch + one dq launch (slabs accumulate).
+    int    range_n, n_ranges, range_tiles, range_ktiles;
+    size_t off_Q, off_tptr, off_stats, off_lse, off_ysum, off_run, off_loss, off_GT, off_Cm, off_slab, off_dcs;
+    size_t score_bytes, lse_bytes, total;
 };
 
 int env_int(const char *name, int dflt)
@@ -137,8 +142,20 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.LDK = lds_ld(g.D16);
     g.ldq = g.D16;
     g.tiles = (N + NT - 1) / NT;
-    g.ldg = g.tiles * NT;
     const int bblks = g.Bpad / BC;
+    // candidate ranges: G^T of one range stays under OKGE_GT_MBYTES (default 1024 MiB)
+    {
+        const int64_t budget = (int64_t)std::max(1, env_int("OKGE_GT_MBYTES", 1024)) << 20;
+        int64_t rt = budget / ((int64_t)g.Bpad * NT * (int64_t)sizeof(float));     // 64-candidate tiles per range
+        rt = std::max<int64_t>(1, std::min<int64_t>(rt, g.tiles));
+        g.range_tiles = (int)rt;
+        g.n_ranges = (g.tiles + g.range_tiles - 1) / g.range_tiles;
+        g.range_tiles = (g.tiles + g.n_ranges - 1) / g.n_ranges;                  // even out the ranges
+        g.n_ranges = (g.tiles + g.range_tiles - 1) / g.range_tiles;
+        g.range_n = g.range_tiles * NT;
+        g.range_ktiles = 2 * g.range_tiles;
+    }
+    g.ldg = g.range_tiles * NT;
     // fused train kernel: 32-candidate tiles, two workgroups per CU; an even tile count so that every
     // 64-candidate chunk dq_kernel reads has been written
     g.tile_w = 32;
@@ -151,22 +168,29 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     bs = std::min(bs, bblks);
     g.b_per_block = (bblks + bs - 1) / bs * BC;
     g.b_split = (g.Bpad + g.b_per_block - 1) / g.b_per_block;
+    if (g.n_ranges > 1) { g.b_split = 1; g.b_per_block = g.Bpad; }   // many tiles: no batch split
     // dQ kernel: (batch block, candidate range) workgroups, two per CU (measured: 512 beats 256 workgroups)
     int ns = std::max(1, 512 / bblks);
     if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
     ns = env_int("OKGE_DQ_SPLIT", ns);
-    ns = std::max(1, std::min(ns, g.tiles));
+    ns = std::max(1, std::min(ns, g.range_tiles));
     g.nsplit = ns;
     size_t off = 0;
+    // [score-only part] the query block
     g.off_Q = off;     off += align_up((size_t)g.Bpad * g.ldq * sizeof(float), 256);
+    g.score_bytes = off;
+    // [row log-sum-exp part] per-range (max, sum-exp) tile statistics + the running per-row state
     g.off_tptr = off;  off += align_up((size_t)(2 * g.tiles + 1) * sizeof(int32_t), 256);
-    g.off_GT = off;    off += align_up((size_t)g.Bpad * g.ldg * sizeof(float), 256);
-    g.off_Cm = off;    off += align_up((size_t)g.tiles * NT * g.D16 * sizeof(float), 256);
-    g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
-    g.off_loss = off;  off += align_up((size_t)2 * g.tiles * g.b_split * sizeof(double), 256);
-    g.off_stats = off; off += align_up((size_t)2 * g.ktiles * g.Bpad * 2 * sizeof(float), 256);
+    g.off_stats = off; off += align_up((size_t)2 * g.range_ktiles * g.Bpad * 2 * sizeof(float), 256);
     g.off_lse = off;   off += align_up((size_t)g.Bpad * sizeof(float), 256);
     g.off_ysum = off;  off += align_up((size_t)g.Bpad * sizeof(float), 256);
+    g.off_run = off;   off += align_up((size_t)g.Bpad * 2 * sizeof(float), 256);
+    g.lse_bytes = off;
+    // [training part]
+    g.off_loss = off;  off += align_up((size_t)2 * g.tiles * g.b_split * sizeof(double), 256);
+    g.off_GT = off;    off += align_up((size_t)g.Bpad * g.ldg * sizeof(float), 256);
+    g.off_Cm = off;    off += align_up((size_t)g.range_tiles * NT * g.D16 * sizeof(float), 256);
+    g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
     g.off_dcs = off;   off += g.b_split > 1 ? align_up((size_t)g.b_split * g.ktiles * 32 * g.D16 * sizeof(float), 256) : 0;
     g.total = off;
     return true;
@@ -202,6 +226,50 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
     a.b_per_block = g.b_per_block;
 }
 
+
+// Arguments of candidate range r (geometry: ranges of g.range_n candidates): local candidate 0 of the launch is
+// candidate r * range_n of the call.  Positives / dropout keep their global columns through cand_col0.
+FusedArgs range_args(const FusedArgs &base, const Geometry &g, int r, int &tiles_r)
+{
+    FusedArgs a = base;
+    const int n_lo = r * g.range_n;
+    a.N = std::min(g.range_n, g.N - n_lo);
+    a.cand_first += n_lo;
+    if (a.cand_ids) a.cand_ids += n_lo;
+    a.cand_col0 += n_lo;
+    if (a.tile_ptr) a.tile_ptr += n_lo / 32;
+    if (a.loss_partial) a.loss_partial += (size_t)(n_lo / 32) * g.b_split;
+    tiles_r = (a.N + NT - 1) / NT;
+    return a;
+}
+
+// per-row log-sum-exp over all candidates of the call (KL loss): one score-statistics pass per candidate range, merged
+// into a running (max, sum-exp) per row; the (B, N) scores are never materialised
+int lse_pass(const Geometry &g, const FusedArgs &base, char *ws, float *row_lse, hipStream_t st)
+{
+    FusedArgs b = base;
+    b.stats = reinterpret_cast<float *>(ws + g.off_stats);
+    b.b_per_block = g.Bpad;
+    b.tile_ptr = nullptr;
+    b.loss_partial = nullptr;
+    for (int r = 0; r < g.n_ranges; ++r) {
+        int tiles_r;
+        const FusedArgs s = range_args(b, g, r, tiles_r);
+        hipError_t e;
+        {
+            ScopedTimer tm("fused_tile_stats", st);
+            e = g.KB <= 16 ? launch_fused(MODE_STATS, s, tiles_r, 1, st) : launch_fused32(MODE_STATS, s, 2 * tiles_r, 1, st);
+            if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
+        }
+        ScopedTimer tm("kl_row_lse", st);
+        // the 64x64 cut emits one (max, sum-exp) per 64-candidate tile, the 32x32 cut one per 16-candidate block
+        e = launch_kl_row_lse(s.stats, g.KB <= 16 ? tiles_r : 4 * tiles_r, g.B, g.Bpad,
+                              reinterpret_cast<float *>(ws + g.off_run), r == 0, r == g.n_ranges - 1, row_lse, st);
+        if (e != hipSuccess) return fail_hip(e, "kl_row_lse");
+    }
+    return OKGE_OK;
+}
+
 }  // namespace
 
 int okge::report_error(int code, const std::string &msg) { return fail(code, msg); }
@@ -219,6 +287,20 @@ size_t okge_train_workspace_bytes(int32_t B, int32_t N, int32_t d)
     return g.total;
 }
 
+size_t okge_score_workspace_bytes(int32_t B, int32_t d)
+{
+    Geometry g;
+    if (!make_geometry(B, 1, d, g)) return 0;
+    return g.score_bytes;
+}
+
+size_t okge_lse_workspace_bytes(int32_t B, int32_t N, int32_t d)
+{
+    Geometry g;
+    if (!make_geometry(B, N, d, g)) return 0;
+    return g.lse_bytes;
+}
+
 int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
                         float *scores, int64_t ld_scores, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -226,7 +308,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     if (!scores || ld_scores < cand->n) return fail(OKGE_ERR_INVALID, "bad scores buffer");
     Geometry g;
     make_geometry(batch->n_po + batch->n_sp, cand->n, t->d, g);
-    const size_t need = g.off_tptr;   // only the query block
+    const size_t need = g.score_bytes;   // only the query block
     if (!workspace || workspace_bytes < need) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
@@ -325,55 +407,50 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     if (loss_kind == OKGE_LOSS_KL) {
         if (sh && !row_lse_ext)
             return fail(OKGE_ERR_INVALID, "sharded KL loss: pass the all-shard row log-sum-exp (okge_row_logsumexp + exchange)");
-        FusedArgs s = a;
-        s.stats = reinterpret_cast<float *>(ws + g.off_stats);
-        s.b_per_block = g.Bpad;
-        if (!row_lse_ext) {
-            ScopedTimer tm("fused_tile_stats", st);
-            e = g.KB <= 16 ? launch_fused(MODE_STATS, s, g.tiles, 1, st) : launch_fused32(MODE_STATS, s, g.ktiles, 1, st);
-            if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
-        }
-        ScopedTimer tm("kl_row_stats", st);
-        // the 64x64 cut emits one (max, sum-exp) per 64-candidate tile, the 32x32 cut one per 16-candidate block
-        // (with an external log-sum-exp only the per-row label mass is computed here: 0 statistic tiles)
-        e = launch_kl_row_stats(s.stats, row_lse_ext ? 0 : (g.KB <= 16 ? g.tiles : 2 * g.ktiles), g.B, g.Bpad, pos->row,
-                                pos->nnz, reinterpret_cast<float *>(ws + g.off_lse),
-                                reinterpret_cast<float *>(ws + g.off_ysum), st);
-        if (e != hipSuccess) return fail_hip(e, "kl_row_stats");
+        if (!row_lse_ext)
+            if (int rc = lse_pass(g, a, ws, reinterpret_cast<float *>(ws + g.off_lse), st)) return rc;
+        ScopedTimer tm("kl_count_pos", st);       // label mass per row (trainer.py:99-101: y is not normalised)
+        e = launch_kl_count_pos(pos->row, pos->nnz, g.Bpad, reinterpret_cast<float *>(ws + g.off_ysum), st);
+        if (e != hipSuccess) return fail_hip(e, "kl_count_pos");
         a.row_lse = row_lse_ext ? row_lse_ext : reinterpret_cast<const float *>(ws + g.off_lse);
         a.row_ysum = reinterpret_cast<const float *>(ws + g.off_ysum);
     }
 #ifdef OKGE_STAMPS
     if (const char *sp = std::getenv("OKGE_STAMPS_PTR")) a.stamps_dbg = reinterpret_cast<unsigned long long *>(std::strtoull(sp, nullptr, 0));
 #endif
-    {
-        ScopedTimer tm("fused_tile_train", st);
-        const int mode = loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE;
-        e = launch_fused32(mode, a, g.ktiles, g.b_split, st);
-        if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
-    }
-    if (g.b_split > 1 && !loss_only) {
-        ScopedTimer tm("dc_reduce", st);
-        e = launch_dc_reduce(a.dC_slab, g.b_split, g.ktiles * 32, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
-                             a.grads_zero, dE, st);
-        if (e != hipSuccess) return fail_hip(e, "dc_reduce");
+    DqArgs q;
+    std::memset(&q, 0, sizeof(q));
+    q.G = a.G; q.Cm = a.Cm;
+    q.slab = reinterpret_cast<float *>(ws + g.off_slab);
+    q.d = g.d; q.KB = g.KB; q.LDK = g.LDK; q.Bpad = g.Bpad; q.ldq = g.ldq; q.ldg = g.ldg;
+    q.nsplit = g.nsplit;
+    const int mode = loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE;
+    for (int r = 0; r < g.n_ranges; ++r) {
+        int tiles_r;
+        const FusedArgs ar = range_args(a, g, r, tiles_r);
+        {
+            ScopedTimer tm("fused_tile_train", st);
+            e = launch_fused32(mode, ar, 2 * tiles_r, g.b_split, st);
+            if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
+        }
+        if (loss_only) continue;
+        if (g.b_split > 1) {                        // (few candidate tiles: always a single range)
+            ScopedTimer tm("dc_reduce", st);
+            e = launch_dc_reduce(a.dC_slab, g.b_split, g.ktiles * 32, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
+                                 a.grads_zero, dE, st);
+            if (e != hipSuccess) return fail_hip(e, "dc_reduce");
+        }
+        ScopedTimer tm("dq", st);
+        q.N = ar.N;
+        q.accumulate = r > 0 ? 1 : 0;               // later ranges add to the slabs of the first
+        e = launch_dq(q, (g.Bpad / BC) * g.nsplit, st);
+        if (e != hipSuccess) return fail_hip(e, "dq_kernel");
     }
     if (loss_only) {
         ScopedTimer tm("loss_reduce", st);
         e = launch_loss_reduce(a.loss_partial, g.ktiles * g.b_split, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "loss_reduce");
         return OKGE_OK;
-    }
-    DqArgs q;
-    std::memset(&q, 0, sizeof(q));
-    q.G = a.G; q.Cm = a.Cm;
-    q.slab = reinterpret_cast<float *>(ws + g.off_slab);
-    q.d = g.d; q.KB = g.KB; q.LDK = g.LDK; q.N = g.N; q.Bpad = g.Bpad; q.ldq = g.ldq; q.ldg = g.ldg;
-    q.nsplit = g.nsplit;
-    {
-        ScopedTimer tm("dq", st);
-        e = launch_dq(q, (g.Bpad / BC) * g.nsplit, st);
-        if (e != hipSuccess) return fail_hip(e, "dq_kernel");
     }
     if (dq_out) {
         ScopedTimer tm("slab_reduce", st);          // + the deterministic loss reduction (one extra workgroup)
@@ -517,26 +594,14 @@ int okge_row_logsumexp(const okge_tables *t, const okge_shard *sh, const float *
     if (!row_lse) return fail(OKGE_ERR_INVALID, "null output");
     Geometry g;
     make_geometry(B, cand->n, t->d, g);
-    if (!workspace || workspace_bytes < g.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+    if (!workspace || workspace_bytes < g.lse_bytes) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
     FusedArgs a;
     fill_fused_common(a, g, t, cand, ws);
     a.Q = Q;
     a.cand_col0 = sh->cand_col0;
-    a.stats = reinterpret_cast<float *>(ws + g.off_stats);
-    a.b_per_block = g.Bpad;
-    hipError_t e;
-    {
-        ScopedTimer tm("fused_tile_stats", st);
-        e = g.KB <= 16 ? launch_fused(MODE_STATS, a, g.tiles, 1, st) : launch_fused32(MODE_STATS, a, g.ktiles, 1, st);
-        if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
-    }
-    ScopedTimer tm("kl_row_stats", st);
-    e = launch_kl_row_stats(a.stats, g.KB <= 16 ? g.tiles : 2 * g.ktiles, g.B, g.Bpad, nullptr, 0, row_lse,
-                            reinterpret_cast<float *>(ws + g.off_ysum), st);
-    if (e != hipSuccess) return fail_hip(e, "kl_row_stats");
-    return OKGE_OK;
+    return lse_pass(g, a, ws, row_lse, st);
 }
 
 int okge_prefix_backward(const okge_tables *t, const okge_shard *sh, const okge_prefix_batch *batch, const float *dQ,

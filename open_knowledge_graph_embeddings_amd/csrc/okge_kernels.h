@@ -45,6 +45,7 @@ struct DqArgs {
     const float   *Cm;         // masked candidate rows written by fused_tile_kernel
     float         *slab;       // [nsplit][Bpad][ldq]
     int32_t        d, KB, LDK, N, Bpad, ldq, ldg, nsplit;
+    int32_t        accumulate; // add to the slabs instead of overwriting them (candidate ranges after the first)
 };
 
 struct PrefixDev {
@@ -72,8 +73,9 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
                                   float *dR, const double *loss_partials, int n_partials, double *loss_out,
                                   hipStream_t st);
 hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
-hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, const int32_t *pos_row, int nnz,
-                               float *row_lse, float *row_ysum, hipStream_t st);
+hipError_t launch_kl_count_pos(const int32_t *pos_row, int nnz, int Bpad, float *row_ysum, hipStream_t st);
+hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, float *run, int first, int last, float *row_lse,
+                             hipStream_t st);
 hipError_t launch_encode_rows(const float *table, int d, const int32_t *ids, int first_id, int n, const DropDev &drop,
                               float *out, int64_t ld_out, hipStream_t st);
 hipError_t launch_scale(float *x, int64_t n, const float *alpha_dev, hipStream_t st);

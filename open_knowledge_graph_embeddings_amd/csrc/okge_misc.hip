@@ -372,12 +372,15 @@ __global__ __launch_bounds__(256) void kl_count_pos_kernel(const int32_t *__rest
 // row log-sum-exp from the per-(tile, row) (max, sum-exp) pairs of the stats pass: one wave per batch row, lanes stride
 // over the tiles (a thread per row walked 2 x tiles strided loads in sequence: 98 us at 228 tiles)
 __global__ __launch_bounds__(256) void kl_row_lse_kernel(const float *__restrict__ stats, int tiles, int B, int Bpad,
+                                                         float2 *__restrict__ run, int first, int last,
                                                          float *__restrict__ row_lse)
 {
+    // candidate ranges: `run` carries the row's (max, sum of exp(x - max)) over the ranges seen so far
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
     const float2 *st = reinterpret_cast<const float2 *>(stats);
     float M = -INFINITY, S = 0.f;                    // running (max, sum of exp(x - max)) of this lane's tiles
+    if (!first && lane == 0) { const float2 v = run[b]; M = v.x; S = v.y; }
     for (int t = lane; t < tiles; t += 64) {
         const float2 v = st[(size_t)t * Bpad + b];
         const float m2 = fmaxf(M, v.x);
@@ -391,7 +394,10 @@ __global__ __launch_bounds__(256) void kl_row_lse_kernel(const float *__restrict
         if (m2 > -INFINITY) S = S * expf(M - m2) + So * expf(Mo - m2);
         M = m2;
     }
-    if (lane == 0) row_lse[b] = M + logf(S);
+    if (lane == 0) {
+        if (last) row_lse[b] = M + logf(S);
+        else run[b] = make_float2(M, S);
+    }
 }
 
 __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, float *__restrict__ g,
@@ -800,14 +806,20 @@ hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, h
     return hipGetLastError();
 }
 
-hipError_t launch_kl_row_stats(const float *stats, int tiles, int B, int Bpad, const int32_t *pos_row, int nnz,
-                               float *row_lse, float *row_ysum, hipStream_t st)
+hipError_t launch_kl_count_pos(const int32_t *pos_row, int nnz, int Bpad, float *row_ysum, hipStream_t st)
 {
     hipError_t e = hipMemsetAsync(row_ysum, 0, sizeof(float) * Bpad, st);
     if (e != hipSuccess) return e;
     if (nnz > 0) hipLaunchKernelGGL(kl_count_pos_kernel, dim3((nnz + 255) / 256), dim3(256), 0, st, pos_row, nnz, row_ysum);
-    if (tiles > 0)
-        hipLaunchKernelGGL(kl_row_lse_kernel, dim3((B + 3) / 4), dim3(256), 0, st, stats, tiles, B, Bpad, row_lse);
+    return hipGetLastError();
+}
+
+hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, float *run, int first, int last, float *row_lse,
+                             hipStream_t st)
+{
+    if (tiles <= 0 || B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kl_row_lse_kernel, dim3((B + 3) / 4), dim3(256), 0, st, stats, tiles, B, Bpad,
+                       reinterpret_cast<float2 *>(run), first, last, row_lse);
     return hipGetLastError();
 }
 

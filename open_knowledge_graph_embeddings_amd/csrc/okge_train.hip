@@ -363,11 +363,14 @@ __global__ __launch_bounds__(DqCfg<KB>::THREADS) void dq_kernel(const DqArgs a)
     for (int i = 0; i < 4; ++i) {
         float *dst = a.slab + ((size_t)split * a.Bpad + b0 + 16 * wq + 4 * s + i) * a.ldq + 16 * KBW * ks;
 #pragma unroll
-        for (int kq = 0; kq < KQ; ++kq)
-            *reinterpret_cast<v4f *>(dst + 64 * kq + 4 * c) =
-                (v4f){acc[4 * kq][i], acc[4 * kq + 1][i], acc[4 * kq + 2][i], acc[4 * kq + 3][i]};
+        for (int kq = 0; kq < KQ; ++kq) {
+            v4f v = (v4f){acc[4 * kq][i], acc[4 * kq + 1][i], acc[4 * kq + 2][i], acc[4 * kq + 3][i]};
+            if (a.accumulate) v += *reinterpret_cast<const v4f *>(dst + 64 * kq + 4 * c);
+            *reinterpret_cast<v4f *>(dst + 64 * kq + 4 * c) = v;
+        }
 #pragma unroll
-        for (int r = 0; r < KR; ++r) dst[64 * KQ + 16 * r + c] = acc[4 * KQ + r][i];
+        for (int r = 0; r < KR; ++r)
+            dst[64 * KQ + 16 * r + c] = a.accumulate ? dst[64 * KQ + 16 * r + c] + acc[4 * KQ + r][i] : acc[4 * KQ + r][i];
     }
 }
 

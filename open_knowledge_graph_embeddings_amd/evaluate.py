@@ -57,7 +57,7 @@ class PipelinedEvaluator:
             pb.n_po, pb.n_sp = b.n_po, b.n_sp
             c.ids = b.cand_ids.data_ptr() if b.cand_ids is not None else None
             c.first_id, c.n = b.cand_first, cb.n_cand
-            ws = eng.workspace(b.B, cb.n_cand, self._t.d)
+            ws = eng.workspace(b.B, cb.n_cand, self._t.d, "score")
             N.check(eng.lib.okge_evaluate_batch(ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c),
                                                 cb.filt_ptr.data_ptr(), cb.filt_col.data_ptr() if cb.filt_col.numel() else None,
                                                 cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(), cb.ids.data_ptr(), n_groups,

@@ -158,8 +158,14 @@ class HotPath:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def workspace(self, B, n_cand, d):
-        need = int(self.lib.okge_train_workspace_bytes(B, n_cand, d))
+    def workspace(self, B, n_cand, d, kind="train"):
+        """scratch for one call; kind 'score' (query block only) and 'lse' are much smaller than 'train'"""
+        if kind == "score":
+            need = int(self.lib.okge_score_workspace_bytes(B, d))
+        elif kind == "lse":
+            need = int(self.lib.okge_lse_workspace_bytes(B, n_cand, d))
+        else:
+            need = int(self.lib.okge_train_workspace_bytes(B, n_cand, d))
         if need == 0:
             raise N.OkgeError(f"invalid problem size B={B} N={n_cand} d={d}")
         if need > self._ws_bytes:
@@ -211,7 +217,7 @@ class HotPath:
         pb, c, keep = self._batch(batch)
         t = self._tables(E, R, scorer)
         B, n = batch.B, c.n
-        ws = self.workspace(B, n, t.d)
+        ws = self.workspace(B, n, t.d, "score")
         if out is None:
             ld = (n + 3) // 4 * 4
             out = torch.empty((B, ld), dtype=torch.float32, device=self.device)[:, :n]
@@ -332,7 +338,7 @@ class HotPath:
         """(B,) log-sum-exp of each query row's scores over the local candidates (scores are not materialised)."""
         pb, c, keep = self._batch(batch)
         t = self._tables(E_local, R, scorer)
-        ws = self.workspace(B, c.n, t.d)
+        ws = self.workspace(B, c.n, t.d, "lse")
         out = torch.empty(B, dtype=torch.float32, device=self.device)
         sh = shard.c()
         N.check(self.lib.okge_row_logsumexp(ctypes.byref(t), ctypes.byref(sh), Q.data_ptr(), Q.stride(0), B,
@@ -410,7 +416,7 @@ class HotPath:
         `ranks` (>= n_groups int64) are caller buffers, `acc` 7 device doubles."""
         pb, c, keep = self._batch(batch)
         t = self._tables(E, R, scorer)
-        ws = self.workspace(batch.B, c.n, t.d)
+        ws = self.workspace(batch.B, c.n, t.d, "score")
         n_groups = int(grp_ptr.numel()) - 1
         N.check(self.lib.okge_evaluate_batch(ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), filt_ptr.data_ptr(),
                                              _ptr(filt_col), row_ptr.data_ptr(), grp_ptr.data_ptr(), ids.data_ptr(),

@@ -35,7 +35,10 @@ Vectors:
   g5_ranks_*      OneToNMentionRelationDataset.compute_metrics (known answer + ties + mention groups)
   g8_checkpoint   the checkpoint dict Trainer.save writes (state_dict + OptimRegime.state_dict()) after two steps,
                   stored with torch.save (tensors / containers only), plus the third step's batch and result
-  g7_traj_*       20 training steps, fixed batches -> loss curve and final tables
+  g7_traj_*       20 training steps, fixed batches -> loss curve and final tables, then compute_metrics on an
+                  evaluation slice of the trained tables (scores, per-group ranks, MRR / MR / Hits)
+  g11_traj_*      30 training steps at the BASELINE size on real FB15k-237 batches (reference dataset + collate), then
+                  filtered ranks / MRR of the first valid.txt batch on the trained tables
 """
 import os
 import sys
@@ -378,6 +381,26 @@ def g7():
         losses.append(loss.item() / float(2 * b * N))
     kw = dict(E0=E0, R0=R0, cand=npy(cand), losses=np.asarray(losses, np.float64),
               E=npy(m.entity_embedding.weight), R=npy(m.relation_embedding.weight), nsteps=np.int64(nsteps))
+    # evaluation slice on the TRAINED tables (trainer.py:258-272 -> dataset.py:423-453): batch 0's prefixes, their
+    # training answers as answer groups (some two-id mention groups), a filter that also hides a few other columns
+    m.eval()
+    po_rel, po_obj, sp_subj, sp_rel, y = batches[0]
+    with torch.no_grad():
+        scores = torch.cat([m.po_prefix_score(po_rel, po_obj), m.sp_prefix_score(sp_subj, sp_rel)], 0)
+    filt = torch.from_numpy(y > 0)
+    label_ids = []
+    for r in range(y.shape[0]):
+        pos = np.flatnonzero(y[r]).astype(np.int32)
+        extra = rng.choice(N, size=3, replace=False)
+        filt[r, torch.from_numpy(extra).long()] = True
+        groups = [torch.IntTensor(pos[i:i + 2]) if (i % 3 == 0 and i + 1 < len(pos)) else torch.IntTensor(pos[i:i + 1])
+                  for i in range(len(pos))]
+        label_ids.append(groups)
+    res = OneToNMentionRelationDataset.compute_metrics(filt, label_ids, scores.clone())
+    rp, gp, gids = pack_groups(label_ids)
+    kw.update(eval_scores=npy(scores), eval_filter=npy(filt).astype(np.uint8), eval_row_ptr=rp, eval_grp_ptr=gp, eval_ids=gids,
+              eval_ranks=per_group_ranks(filt, label_ids, scores.clone()),
+              **{"eval_m_" + k: np.float64(v.avg) for k, v in res.items()})
     for i, (a, b_, c, e, y) in enumerate(batches):
         kw.update({f"b{i}_po_rel": npy(a), f"b{i}_po_obj": npy(b_), f"b{i}_sp_subj": npy(c), f"b{i}_sp_rel": npy(e),
                    f"b{i}_labels": y})
@@ -660,6 +683,125 @@ def g10():
 
 
 # ----------------------------------------------------------------------------------------------
+# G11: training trajectory at the BASELINE size on real FB15k-237 batches, then filtered MRR on the trained tables
+# ----------------------------------------------------------------------------------------------
+def g11():
+    """30 optimisation steps of the reference (LookupComplexRelationModel d=200, AddLossModule bce, OptimRegime Adagrad
+    lr 0.3 wd 1e-10, dropout 0) on 512-prefix batches that its own dataset class + collate produce from test.txt (the
+    stand-in training split; train.txt is absent upstream), then Trainer.evaluate's arithmetic (eval-mode prefix scores
+    -> compute_metrics) on the first 512-prefix batch of valid.txt: loss curve, table checksums + slices, per-group
+    ranks, MRR / MR / Hits."""
+    import shutil
+    import tempfile
+    from openkge.dataset import OneToNMentionRelationDataset_collate_func as collate
+    fb = "/root/reference/data/fb15k237/mapped_to_ids"
+    scratch = tempfile.mkdtemp(prefix="okge_g11_")
+    nsteps, half = 30, 256
+    try:
+        for f in os.listdir(fb):
+            shutil.copy(os.path.join(fb, f), scratch)
+        files = {"train": "test.txt", "valid": "valid.txt", "test": "test.txt"}
+        ds = {}
+        for split in ("train", "valid"):
+            ds[split] = OneToNMentionRelationDataset(dataset_dir=scratch, input_file=files[split],
+                                                     is_training_data=(split == "train"), batch_size=512, copy_data_to_dev_shm=False)
+        for split in ("train", "valid"):
+            ds[split].merge_all_splits_triples(dataset_dir=scratch, train_input_file=files["train"],
+                                               valid_input_file=files["valid"], test_input_file=files["test"])
+            ds[split].create_data_tensors(dataset_dir=scratch, train_input_file=files["train"],
+                                          valid_input_file=files["valid"], test_input_file=files["test"])
+        tr, v = ds["train"], ds["valid"]
+        n_ent, n_rel = v.entity_vocab_size, v.relations_size
+
+        def batch_of(dset, step, training):
+            pref = dset.seen_prefixes_tensor
+            slot = pref[:, 6]
+            po_rows, sp_rows = torch.nonzero(slot == 0).view(-1), torch.nonzero(slot == 2).view(-1)
+            rows = torch.cat([po_rows[step * half:(step + 1) * half], sp_rows[step * half:(step + 1) * half]])
+            assert len(rows) == 2 * half
+            return collate(use_batch_shared_entities=False, sp_po__batch=[pref[i] for i in rows.tolist()],
+                           entity_vocab_size=n_ent, entity_vocab_offset=2, is_training_data=training,
+                           this_split_entities_list=dset.seen_entities_tensor,
+                           all_splits_entities_tensor=dset.all_splits_entities_tensor, min_size_batch_labels=0)
+
+        train_batches = [batch_of(tr, t, True) for t in range(nsteps)]
+        eval_batch = batch_of(v, 0, False)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    seed, d = 2025, 200
+    m = make_model("LookupComplexRelationModel", n_ent, n_rel, d, seed=seed, init_std=0.1)
+    E0, R0 = npy(m.entity_embedding.weight).copy(), npy(m.relation_embedding.weight).copy()
+    m.train()
+    args = {"optimization_config": {"optimizer": "Adagrad", "epoch": 0, "lr": 0.3, "weight_decay": 1.0e-10},
+            "lr_scheduler_config": None}
+    opts = OptimRegime.setup_optimizer_regime(args=args, model=m)
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+    mod.train()
+    kw, losses = {}, []
+    for step, out in enumerate(train_batches):
+        inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = out
+        for o in opts:
+            o.update(1, step + 1)
+            o.zero_grad()
+        loss, _, _ = mod(inputs=list(inputs), labels=labels.clone(), use_batch_shared_entities=False,
+                         batch_shared_entities=cand, epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+        (loss.sum() / float(norm_loss)).backward()
+        for o in opts:
+            o.step()
+        losses.append(loss.item())
+        kw.update({f"s{step}_po_rel": npy(inputs[0][0]).reshape(-1), f"s{step}_po_obj": npy(inputs[0][1]).reshape(-1),
+                   f"s{step}_sp_subj": npy(inputs[1][0]).reshape(-1), f"s{step}_sp_rel": npy(inputs[1][1]).reshape(-1),
+                   f"s{step}_labels": npy(labels.nonzero()).astype(np.int32), f"s{step}_normalizer": np.float64(norm_loss)})
+    E, R = npy(m.entity_embedding.weight), npy(m.relation_embedding.weight)
+    sumE = npy(opts[0].optimizer.state[m.entity_embedding.weight]["sum"])
+    m.eval()
+    inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = eval_batch
+    with torch.no_grad():
+        scores = torch.cat([m.po_prefix_score(inputs[0][0], inputs[0][1]), m.sp_prefix_score(inputs[1][0], inputs[1][1])], 0)
+    res = OneToNMentionRelationDataset.compute_metrics(filter_mask=filt, label_ids=label_ids, predictions=scores.clone())
+    rp, gp, gids = pack_groups(label_ids)
+    chk = lambda a: np.asarray([a.sum(dtype=np.float64), np.abs(a).sum(dtype=np.float64), (a.astype(np.float64) ** 2).sum()])  # noqa: E731
+    # the same evaluation against a 2048-candidate SUBSET (every answer and filter column of the batch + random fill),
+    # with the trained rows it needs stored: ranks on IDENTICAL trained tables can then be compared without the 11.6 MB
+    # table (many_obj / many_subj path of the prefix scorers, model.py:52-74)
+    rng = np.random.default_rng(seed)
+    need = set(int(x) for g in label_ids for grp in g for x in grp.tolist()) | set(npy(filt.nonzero())[:, 1].tolist())
+    fill = [int(x) for x in rng.permutation(n_ent - 2) if int(x) not in need][:2048 - len(need)]
+    sub_cols = np.sort(np.asarray(sorted(need) + fill, np.int64))              # candidate-relative (entity id - 2)
+    assert len(sub_cols) == 2048
+    col_to_sub = -np.ones(n_ent - 2, np.int64)
+    col_to_sub[sub_cols] = np.arange(len(sub_cols))
+    sub_ids = torch.from_numpy((sub_cols + 2).astype(np.int32)).unsqueeze(1)
+    with torch.no_grad():
+        enc = m.precompute_batch_shared_inputs(sub_ids.view(-1))              # as AddLossModule does, trainer.py:80-82
+        sub_scores = torch.cat([m.po_prefix_score(inputs[0][0], inputs[0][1], enc),
+                                m.sp_prefix_score(inputs[1][0], inputs[1][1], enc)], 0)
+    sub_filt = filt[:, torch.from_numpy(sub_cols)]
+    sub_label_ids = [[torch.from_numpy(col_to_sub[grp.long().numpy()]).int() for grp in g] for g in label_ids]
+    sub_res = OneToNMentionRelationDataset.compute_metrics(filter_mask=sub_filt, label_ids=sub_label_ids, predictions=sub_scores.clone())
+    srp, sgp, sgids = pack_groups(sub_label_ids)
+    row_ids = np.unique(np.concatenate([sub_cols + 2, npy(inputs[0][1]).reshape(-1), npy(inputs[1][0]).reshape(-1)])).astype(np.int64)
+    kw.update(sub_cand_ids=(sub_cols + 2).astype(np.int32), sub_filter=npy(sub_filt.nonzero()).astype(np.int32),
+              sub_row_ptr=srp, sub_grp_ptr=sgp, sub_ids=sgids, sub_ranks=per_group_ranks(sub_filt, sub_label_ids, sub_scores.clone()),
+              sub_scores_slice=npy(sub_scores[192:320, 1000:1128]), sub_m_mrr=np.float64(sub_res["mrr"].avg),
+              trained_row_ids=row_ids, trained_rows=E[row_ids].copy())
+    save("g11_traj_fb15k237", seed=np.int64(seed), n_ent=np.int64(n_ent), n_rel=np.int64(n_rel), d=np.int64(d),
+         nsteps=np.int64(nsteps), lr=np.float64(0.3),
+         table_check=np.asarray([E0.sum(dtype=np.float64), np.abs(E0).sum(dtype=np.float64), R0.sum(dtype=np.float64),
+                                 float(E0[5, 7]), float(E0[-1, -1]), float(R0[3, 4])], np.float64),
+         losses=np.asarray(losses, np.float64), E_check=chk(E), R_check=chk(R), sumE_check=chk(sumE),
+         E_rows=E[2:66].copy(), E_row_ids=np.arange(2, 66), R_final=R.copy(),
+         E_col_sum=E.astype(np.float64).sum(0), E_row_sum=E.astype(np.float64).sum(1),
+         eval_po_rel=npy(inputs[0][0]).reshape(-1), eval_po_obj=npy(inputs[0][1]).reshape(-1),
+         eval_sp_subj=npy(inputs[1][0]).reshape(-1), eval_sp_rel=npy(inputs[1][1]).reshape(-1),
+         eval_filter=npy(filt.nonzero()).astype(np.int32), eval_row_ptr=rp, eval_grp_ptr=gp, eval_ids=gids,
+         eval_ranks=per_group_ranks(filt, label_ids, scores.clone()),
+         eval_score_slice=npy(scores[192:320, 1000:1128]), eval_score_row_absmax=npy(scores.abs().max(1).values),
+         **{"eval_m_" + k: np.float64(v.avg) for k, v in res.items()},
+         **{"eval_c_" + k: np.float64(v.count) for k, v in res.items()}, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
 # G8: checkpoint interop (Trainer.save layout, trainer.py:608-618)
 # ----------------------------------------------------------------------------------------------
 def g8():
@@ -705,7 +847,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)
