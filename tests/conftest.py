@@ -14,10 +14,31 @@ os.environ.setdefault("OKGE_VALIDATE", "1")      # tests check id ranges before 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "both: host-side parity test (no GPU needed) that ALSO runs under `-m gpu`, so the "
+                                       "GPU-box record covers the batch producer / file loader / checkpoint rows")
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` also selects the tests marked `both` (they run in the CPU suite as well)"""
+    if (config.getoption("-m") or "").strip() == "gpu":
+        for it in items:
+            if it.get_closest_marker("both") is not None:
+                it.add_marker(pytest.mark.gpu)
 
 
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def fb15k237_dir(tmp_path):
+    """the reference's FB15k-237 id files valid.txt / test.txt (data fixtures, tests/golden/fb15k237/*.gz) unpacked"""
+    import gzip
+    import shutil
+    for f in ("valid.txt", "test.txt"):
+        with gzip.open(os.path.join(GOLDEN, "fb15k237", f + ".gz"), "rb") as src, open(os.path.join(tmp_path, f), "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    return str(tmp_path)
 
 
 def golden_names(prefix):

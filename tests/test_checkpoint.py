@@ -27,6 +27,7 @@ def structure(x):
     return x
 
 
+@pytest.mark.both
 def test_roundtrip_layout_equals_reference_checkpoint():
     from open_knowledge_graph_embeddings_amd.checkpoint import load_reference_checkpoint, to_reference_checkpoint
     path = os.path.join(GOLDEN_DIR, "g8_checkpoint_after.pt")
@@ -48,6 +49,7 @@ def test_roundtrip_layout_equals_reference_checkpoint():
         load_reference_checkpoint(HostStep(n_ent=91), mine)
 
 
+@pytest.mark.both
 def test_reference_can_load_our_checkpoint_structure(tmp_path):
     """torch.optim.Adagrad.load_state_dict accepts the optimizer_state we write (it is what OptimRegime hands it,
     utils/optim.py:193) and model.load_state_dict-style key lookup finds both tables."""

@@ -33,6 +33,7 @@ def coords(b):
     return rc[np.lexsort((rc[:, 1], rc[:, 0]))]
 
 
+@pytest.mark.both
 def test_collate_matches_reference_cases(okge_lib):
     n = 0
     for z, t, shared, min_size, training in cases():
@@ -192,6 +193,7 @@ def test_producer_feeds_train_step_and_ranks(okge_lib, shared):
 
 
 # --------------------------------------------------------------------------------- on-disk format -> tensors (f3)
+@pytest.mark.both
 def test_dataset_loader_matches_reference_tensors(okge_lib):
     """csrc/okge_dataset.cpp on tests/golden/toy_kg against the tensors the reference's dataset class built from the
     same files (tests/golden/g6_dataset_toy.npz), and against the oracle restatement."""
@@ -220,13 +222,14 @@ def test_dataset_loader_matches_reference_tensors(okge_lib):
     np.testing.assert_array_equal(out3["valid"][0], out["valid"][0])
 
 
-def test_dataset_loader_fb15k237_hashes(okge_lib):
-    """The reference's own FB15k-237 files (present only where /root/reference is mounted; skipped elsewhere)."""
+@pytest.mark.both
+def test_dataset_loader_fb15k237_hashes(okge_lib, tmp_path):
+    """The reference's own FB15k-237 id files (data fixtures under tests/golden/fb15k237): the loader's tensors are
+    sha256-identical to what the reference's dataset class built from them (G6)."""
     import hashlib
+    from conftest import fb15k237_dir
     from open_knowledge_graph_embeddings_amd.dataset import load_dataset_tensors
-    fb = "/root/reference/data/fb15k237/mapped_to_ids"
-    if not os.path.isdir(fb):
-        pytest.skip("reference data not mounted")
+    fb = fb15k237_dir(tmp_path)
     z = golden("g6_dataset_fb15k237_hashes")
     out, all_splits, _ = load_dataset_tensors(fb, train_input_file="test.txt")       # train split absent upstream
     pref, seen = out["valid"]
@@ -248,6 +251,7 @@ def test_dataset_loader_errors(okge_lib, tmp_path):
         load_dataset_tensors(str(tmp_path))                                            # a short line
 
 
+@pytest.mark.both
 def test_files_to_batches_end_to_end(okge_lib):
     """toy_kg text files -> loader -> producer -> batches, against the oracle fed with the reference-built tensors"""
     import os
