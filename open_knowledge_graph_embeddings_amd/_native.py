@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libokge_hip.so")
-SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_misc.hip", "okge_pool.hip", "okge_collate.cpp", "okge_dataset.cpp"]
+SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_train64.hip", "okge_misc.hip", "okge_pool.hip", "okge_collate.cpp", "okge_dataset.cpp"]
 HEADERS = ["okge_device.h", "okge_kernels.h", os.path.join("..", "..", "include", "okge.h")]
 
 OKGE_COMPLEX, OKGE_DISTMULT = 0, 1

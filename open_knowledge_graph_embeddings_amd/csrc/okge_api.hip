@@ -156,11 +156,12 @@ bool make_geometry(int B, int N, int d, Geometry &g)
         g.range_ktiles = 2 * g.range_tiles;
     }
     g.ldg = g.range_tiles * NT;
-    // fused train kernel: 32-candidate tiles, two workgroups per CU; an even tile count so that every
-    // 64-candidate chunk dq_kernel reads has been written
-    g.tile_w = 32;
-    g.ktiles = 2 * g.tiles;
-    const int slots = 512;
+    // fused train kernel: one 8-wave workgroup per CU on 64-candidate tiles (slot sizes up to 256), or the 32-candidate
+    // cut for larger slots (an even tile count so that every 64-candidate chunk dq_kernel reads has been written)
+    g.tile_w = g.KB <= 16 ? 64 : 32;
+    g.tile_w = env_int("OKGE_TILE_W", g.tile_w) == 32 ? 32 : g.tile_w;      // diagnostic: the round-1 cut
+    g.ktiles = g.tiles * (NT / g.tile_w);
+    const int slots = g.tile_w == 64 ? 256 : 512;
     // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y
     int bs = 1;
     if (g.ktiles < slots * 3 / 4) bs = std::min(bblks, (slots + g.ktiles - 1) / g.ktiles);
@@ -191,7 +192,7 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.off_GT = off;    off += align_up((size_t)g.Bpad * g.ldg * sizeof(float), 256);
     g.off_Cm = off;    off += align_up((size_t)g.range_tiles * NT * g.D16 * sizeof(float), 256);
     g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
-    g.off_dcs = off;   off += g.b_split > 1 ? align_up((size_t)g.b_split * g.ktiles * 32 * g.D16 * sizeof(float), 256) : 0;
+    g.off_dcs = off;   off += g.b_split > 1 ? align_up((size_t)g.b_split * g.tiles * NT * g.D16 * sizeof(float), 256) : 0;
     g.total = off;
     return true;
 }
@@ -237,8 +238,8 @@ FusedArgs range_args(const FusedArgs &base, const Geometry &g, int r, int &tiles
     a.cand_first += n_lo;
     if (a.cand_ids) a.cand_ids += n_lo;
     a.cand_col0 += n_lo;
-    if (a.tile_ptr) a.tile_ptr += n_lo / 32;
-    if (a.loss_partial) a.loss_partial += (size_t)(n_lo / 32) * g.b_split;
+    if (a.tile_ptr) a.tile_ptr += n_lo / g.tile_w;
+    if (a.loss_partial) a.loss_partial += (size_t)(n_lo / g.tile_w) * g.b_split;
     tiles_r = (a.N + NT - 1) / NT;
     return a;
 }
@@ -430,13 +431,13 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         const FusedArgs ar = range_args(a, g, r, tiles_r);
         {
             ScopedTimer tm("fused_tile_train", st);
-            e = launch_fused32(mode, ar, 2 * tiles_r, g.b_split, st);
+            e = g.tile_w == 64 ? launch_fused64(mode, ar, tiles_r, g.b_split, st) : launch_fused32(mode, ar, 2 * tiles_r, g.b_split, st);
             if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
         }
         if (loss_only) continue;
         if (g.b_split > 1) {                        // (few candidate tiles: always a single range)
             ScopedTimer tm("dc_reduce", st);
-            e = launch_dc_reduce(a.dC_slab, g.b_split, g.ktiles * 32, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
+            e = launch_dc_reduce(a.dC_slab, g.b_split, g.tiles * NT, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
                                  a.grads_zero, dE, st);
             if (e != hipSuccess) return fail_hip(e, "dc_reduce");
         }

@@ -42,7 +42,7 @@ struct FusedArgs {
 
 struct DqArgs {
     const float   *G;
-    const float   *Cm;         // masked candidate rows written by fused_tile_kernel
+    const float   *Cm;         // masked candidate rows written by the tile kernel
     float         *slab;       // [nsplit][Bpad][ldq]
     int32_t        d, KB, LDK, N, Bpad, ldq, ldg, nsplit;
     int32_t        accumulate; // add to the slabs instead of overwriting them (candidate ranges after the first)
@@ -60,6 +60,7 @@ size_t     dq_shmem_bytes(int LDK);
 hipError_t launch_fused(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st);
 hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
+hipError_t launch_fused64(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,

@@ -282,12 +282,13 @@ template <int KB> struct DqCfg {
 
 template <int KB>
 __device__ __forceinline__ void dq_prefetch(v4f (&gv)[DqCfg<KB>::GV], v4f (&cv)[4 * DqCfg<KB>::NOIT],
-                                            const float *__restrict__ g_blk, const float *__restrict__ cm, int tid)
+                                            const float *__restrict__ g_blk, const DqArgs &a, int ch, int tid)
 {
     using Cfg = DqCfg<KB>;
     constexpr int NO = Cfg::NO, NOIT = Cfg::NOIT, QG = Cfg::QG;
 #pragma unroll
     for (int it = 0; it < Cfg::GV; ++it) gv[it] = *reinterpret_cast<const v4f *>(g_blk + (size_t)(tid + it * Cfg::THREADS) * 4);
+    const float *cm = a.Cm + (size_t)ch * NT * (16 * KB);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int r = tid / QG + 32 * pass;
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(DqCfg<KB>::THREADS) void dq_kernel(const DqArgs a)
     // register-staged prefetch: the next chunk's G block and masked candidate tile are in flight during the MFMAs
     v4f gv[Cfg::GV], cv[4 * NOIT];   // cv[(2*pass + half) * NOIT + it]
     auto g_block = [&](int ch) { return a.G + ((size_t)ch * nJ + bblk) * 4096; };
-    if (ch_lo < ch_hi) dq_prefetch<KB>(gv, cv, g_block(ch_lo), a.Cm + (size_t)ch_lo * NT * (16 * KB), tid);
+    if (ch_lo < ch_hi) dq_prefetch<KB>(gv, cv, g_block(ch_lo), a, ch_lo, tid);
     for (int ch = ch_lo; ch < ch_hi; ++ch) {
         // G^T block -> LDS (float4 number f: candidate f >> 4, batch rows 4 * (f & 15) ..)
 #pragma unroll
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(DqCfg<KB>::THREADS) void dq_kernel(const DqArgs a)
             }
         }
         __syncthreads();
-        if (ch + 1 < ch_hi) dq_prefetch<KB>(gv, cv, g_block(ch + 1), a.Cm + (size_t)(ch + 1) * NT * (16 * KB), tid);
+        if (ch + 1 < ch_hi) dq_prefetch<KB>(gv, cv, g_block(ch + 1), a, ch + 1, tid);
         // A[i = b][slot s, step t] = G^T[n = 16s + t][b = 16wq + c] ; B[slot][k] = C[n = 16s + t][k of this wave's half]
         grad_product<KBW, false, LDK>(acc, Gt + 16 * s * LDGT + 16 * wq + c, LDGT, Cs + 16 * s * LDK + 16 * KBW * ks, c);
         __syncthreads();

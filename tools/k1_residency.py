@@ -21,7 +21,8 @@ E, R = synthetic.make_tables(w)
 step = FusedTrainStep(torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev), w.scorer, lr=w.lr,
                       input_dropout=w.input_dropout, seed=1)
 batches = [bench.to_dev_batch(synthetic.make_batch(w, seed=i), w, dev) for i in range(4)]
-tiles = 2 * ((w.N + 63) // 64)
+tile_w = int(os.environ.get("OKGE_TILE_W", "64"))
+tiles = (64 // tile_w) * ((w.N + 63) // 64)
 buf = torch.zeros(tiles * 4, dtype=torch.int64, device=dev)
 os.environ["OKGE_STAMPS_PTR"] = hex(buf.data_ptr())
 for i in range(5):

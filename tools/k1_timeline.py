@@ -20,7 +20,8 @@ E, R = synthetic.make_tables(w)
 step = FusedTrainStep(torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev), w.scorer, lr=w.lr,
                       input_dropout=w.input_dropout, seed=1)
 batches = [bench.to_dev_batch(synthetic.make_batch(w, seed=i), w, dev) for i in range(4)]
-tiles = 2 * ((w.N + 63) // 64)
+tile_w = int(os.environ.get("OKGE_TILE_W", "64"))
+tiles = (64 // tile_w) * ((w.N + 63) // 64)
 buf = torch.zeros(tiles * 4 + tiles * 80, dtype=torch.int64, device=dev)
 os.environ["OKGE_STAMPS_PTR"] = hex(buf.data_ptr())
 for i in range(3):
@@ -29,6 +30,22 @@ torch.cuda.synchronize()
 a = buf.cpu().numpy()
 head = a[: tiles * 4].reshape(-1, 4)
 tl = a[tiles * 4:].reshape(-1, 80)
+if tile_w == 64:
+    for wg in (int(sys.argv[1]) if len(sys.argv) > 1 else 5,):
+        base = head[wg, 0]
+        print(f"WG {wg}: start 0 end {head[wg,1]-base}")
+        print("chunk | staged  barrier->P1start  P1end  P2end | P1 dur  epi+P2 dur  wait@barrier  period")
+        prev = None
+        for ch in range(8):
+            r = tl[wg, 4 * ch: 4 * ch + 4] - base
+            print(f"{ch:3d}  {r[0]:7d} {r[1]:7d} {r[2]:7d} {r[3]:7d} | {r[2]-r[1]:6d} {r[3]-r[2]:6d} {r[1]-r[0]:6d} "
+                  f"{(r[1]-prev) if prev is not None else 0:6d}")
+            prev = r[1]
+        print("loop done at", tl[wg, 32] - base)
+        pe = tl[wg, 40:45] - base
+        print(f"prologue: gather loads issued {pe[0]}, tile parked in LDS {pe[1]}, barrier passed {pe[2]}")
+        print(f"epilogue: partial sums combined {pe[3]}, loss partial out {pe[4]}, workgroup end {head[wg,1]-base}")
+    sys.exit(0)
 for wg in (int(sys.argv[1]) if len(sys.argv) > 1 else 5,):
     A, B = wg, wg + 256
     base = min(head[A, 0], head[B, 0])
