@@ -13,7 +13,8 @@ All inputs (tables, batches) are resident in HBM before the timed region.  Rank 
 N > 1: the entity table (and its Adagrad state) is row-sharded over the N GPUs and every rank scores the SAME
 global batch of 512*N prefixes against its own candidates (open_knowledge_graph_embeddings_amd/sharded.py:
 two small RCCL all-reduces per step).  Per-GPU work is constant in N ("weak" scaling); `value` counts each
-global batch once.
+global batch once.  The line also carries an `olp` object: the north-star's second shape (S-OLP, |E| = 2.5 M, d = 256,
+B = 4096, Zipf(1.1) prefix entities) at the SAME global size for every N (strong scaling), a handful of steps.
 """
 import argparse
 import json
@@ -101,6 +102,56 @@ def cpu_baseline(w, host_batches, budget_s=20.0):
             "sample": f"{steps} steps of {w.name} (B={w.B}, N={w.N}, d={w.d}) in {el:.1f}s, torch-CPU twin of the "
                       f"reference op sequence, dense labels prebuilt, no dataloader",
             "ms_per_step": 1e3 * el / steps}
+
+
+def run_olp(world, rank, dev, dist, barrier, steps=6, warmup=2):
+    """S-OLP at the full size on `world` GPUs: tables generated on the device from per-row-block seeds (identical for
+    every N), Zipf(1.1) prefix entity ids, one positive per row, dropout 0 (the reference's OLPBENCH
+    configs train without input dropout), BCE, dense Adagrad.  Returns the sub-object rank 0 prints."""
+    from open_knowledge_graph_embeddings_amd import synthetic
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+    w = synthetic.WORKLOADS["S-OLP"]
+    host_batches = [synthetic.make_batch(w, seed=4321 + i, zipf=True) for i in range(4)]
+    batches = [to_dev_batch(hb, w, dev) for hb in host_batches]
+    n_pos = [hb["n_pos"] for hb in host_batches]
+
+    def table(rows_lo, rows_hi, d, seed):            # same values whatever the sharding: 65536-row blocks, one seed each
+        out = torch.empty((rows_hi - rows_lo, d), dtype=torch.float32, device=dev)
+        blk = 65536
+        for b0 in range(rows_lo // blk * blk, rows_hi, blk):
+            g = torch.Generator(device=dev).manual_seed(seed + b0 // blk)
+            t = torch.randn((blk, d), generator=g, device=dev, dtype=torch.float32) * w.init_std
+            lo, hi = max(b0, rows_lo), min(b0 + blk, rows_hi)
+            out[lo - rows_lo:hi - rows_lo] = t[lo - b0:hi - b0]
+        return out
+
+    Rt = table(0, w.n_rel, w.d, 99)
+    if world > 1:
+        from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep, shard_range
+        lo, hi = shard_range(w.n_ent, world, rank)
+        step = ShardedTrainStep(table(lo, hi, w.d, 7), Rt, w.scorer, w.n_ent, lr=w.lr, loss=w.loss, seed=1234)
+    else:
+        step = FusedTrainStep(table(0, w.n_ent, w.d, 7), Rt, w.scorer, loss=w.loss, lr=w.lr, seed=1234)
+    for i in range(warmup):
+        step.step(batches[i % 4])
+    barrier()
+    t0 = time.perf_counter()
+    triples = 0
+    for i in range(steps):
+        step.step(batches[i % 4])
+        triples += n_pos[i % 4]
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax[0].item())
+    flops = 6.0 * w.B * w.N * w.d
+    return {"workload": f"S-OLP: OLPBENCH-shaped |E|={w.n_ent} |R|={w.n_rel} d={w.d} ComplEx 1-vs-all, B={w.B}, Zipf(1.1) prefix "
+                        f"entities, BCE, dense Adagrad", "scaling": "strong", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * el / steps, "value": triples / el, "unit": "triples/s", "prefixes_per_s": w.B * steps / el,
+            "step_frac": flops / (el / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS / world,
+            "parallelism": f"entity table row-sharded x{world}" if world > 1 else "single"}
 
 
 def main():
@@ -214,20 +265,27 @@ def main():
         n_local = step.n_cand_local if sharded else w.N
         flops = 4.0 * w_run.B * n_local * w.d         # X = Q.C^T (2BNd) + dC = G^T.Q (2BNd) per launch, this rank
         achieved = flops / avg_s / 1e12
-        # HBM bytes per launch of that kernel from the committed PMC passes of this same command
-        # (tools/collect_profiles.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled as the gfx950 guide says)
-        traffic = None
+        # HBM bytes per launch of that kernel: from the committed PMC passes of this same command (tools/collect_profiles.sh:
+        # separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled as the gfx950 guide says); counters cannot be read inside
+        # a timed run, so the value is tagged with the file and the commit it was collected at
+        traffic, traffic_src = None, None
+        kname = "fused_tile64_kernel" if w.d <= 256 else "fused_tile32_kernel"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and not sharded and args.workload == "S-FB":
             tj = json.load(open(tpath))
-            hit = [v for k, v in tj.items() if k.startswith("fused_tile32_kernel")]
+            hit = [v for k, v in tj.items() if k.startswith(kname)]
             if hit:
                 traffic = hit[0]["hbm_bytes_per_launch"]
-        roof = {"bound": "mfma", "kernel": "fused_tile32_kernel<train>", "achieved": achieved,
+                traffic_src = {"file": "profiles/pmc_traffic.json", "collected_at_commit": tj.get("_commit"),
+                               "command": tj.get("_command"), "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"}
+        step_s = elapsed / args.steps
+        roof = {"bound": "mfma", "kernel": kname + "<train>", "achieved": achieved,
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": traffic, "avg_launch_us": avg_s * 1e6,
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": avg_s * 1e6,
                 "kernels_us": {k: v[0] / v[1] * 1e3 for k, v in per_kernel.items()},
-                "step_flops_6BNd": 6.0 * w_run.B * n_local * w.d, "step_bytes_20Nd": 20.0 * n_local * w.d}
+                "step_flops_6BNd": 6.0 * w_run.B * n_local * w.d, "step_bytes_20Nd": 20.0 * n_local * w.d,
+                # the whole step against the same peak: 6 B N d flops (this rank's candidates) / measured step time
+                "step_frac": 6.0 * w_run.B * n_local * w.d / step_s / 1e12 / FP32_MFMA_PEAK_TFLOPS}
 
     # ---- evaluation leg (single GPU): score every candidate + filtered ranks (dataset.py:423-446) --------------
     ev = None
@@ -251,6 +309,14 @@ def main():
         ev = {"ms_per_batch": 1e3 * el / n_it, "prefixes_per_s": w.B * n_it / el, "groups": n_groups // n_it,
               "mrr": res["mrr"].avg}
 
+    # ---- the north-star's second shape: S-OLP (|E| = 2.5 M, |R| = 100 k, d = 256, B = 4096, Zipf(1.1) prefix entities),
+    #      the SAME global problem at every N (strong scaling), entity table row-sharded over the ranks; a handful of steps
+    olp = None
+    if args.workload == "S-FB" and os.environ.get("OKGE_BENCH_OLP", "1") == "1":
+        del step, batches, Et, Rt
+        torch.cuda.empty_cache()
+        olp = run_olp(world, rank, dev, dist, barrier)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -269,7 +335,7 @@ def main():
                    "global_batch": w_run.B,
                    "parallelism": f"entity table row-sharded x{world}, batch 512 x{world}" if sharded else "single"},
         "prefixes_per_s": w_run.B * args.steps / elapsed, "last_loss_sum": loss_last,
-        "roofline": roof, "cpu_baseline": cpu, "eval": ev,
+        "roofline": roof, "cpu_baseline": cpu, "eval": ev, "olp": olp,
     }
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
