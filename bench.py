@@ -295,19 +295,26 @@ def main():
         t = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
         csr = [t(hb[k]) for k in ("filt_ptr", "filt_col", "row_ptr", "grp_ptr", "ids")]
         from open_knowledge_graph_embeddings_amd.dataset import CollatedBatch
-        from open_knowledge_graph_embeddings_amd.evaluate import PipelinedEvaluator
+        from open_knowledge_graph_embeddings_amd.evaluate import FusedEvaluator, PipelinedEvaluator
         cb = CollatedBatch(eb, float(w.B * w.N), float(hb["n_pos"]), w.N, row_ptr=csr[2], grp_ptr=csr[3], ids=csr[4],
                            filt_ptr=csr[0], filt_col=csr[1])
-        ev_run = PipelinedEvaluator(Et, Rt, w.scorer, engine=step.engine)
-        ev_run.run([cb] * 4)
-        torch.cuda.synchronize()
         n_it = 40
-        t0 = time.perf_counter()
-        res, n_groups = ev_run.run([cb] * n_it)           # score on one stream, ranks + meters on another (evaluate.py)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        ev = {"ms_per_batch": 1e3 * el / n_it, "prefixes_per_s": w.B * n_it / el, "groups": n_groups // n_it,
-              "mrr": res["mrr"].avg}
+        ev = {}
+        # fused: point scores + tile sweep counting in registers + ranks/meters, no (B, N) score block (okge_evaluate_fused);
+        # pipelined: the materialising path (scores on one stream, ranks + meters on another), kept for d > 256 / dropout
+        for name, cls in (("fused", FusedEvaluator), ("pipelined", PipelinedEvaluator)):
+            ev_run = cls(Et, Rt, w.scorer, engine=step.engine)
+            ev_run.run([cb] * 4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res, n_groups = ev_run.run([cb] * n_it)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if name == "fused":
+                ev.update({"ms_per_batch": 1e3 * el / n_it, "prefixes_per_s": w.B * n_it / el, "groups": n_groups // n_it,
+                           "mrr": res["mrr"].avg, "path": "okge_evaluate_fused"})
+            else:
+                ev.update({"pipelined_ms_per_batch": 1e3 * el / n_it, "pipelined_mrr": res["mrr"].avg})
 
     # ---- the north-star's second shape: S-OLP (|E| = 2.5 M, |R| = 100 k, d = 256, B = 4096, Zipf(1.1) prefix entities),
     #      the SAME global problem at every N (strong scaling), entity table row-sharded over the ranks; a handful of steps

@@ -792,21 +792,34 @@ int okge_rank_metrics(const int64_t *ranks, int64_t n, double *acc, void *stream
 
 // One evaluation batch on two streams: scores on `stream`, ranks + meters on `rank_stream`, ordered by events the
 // library owns.  A score buffer is reused only after the ranks of the batch that last used it are counted.
+}  // extern "C"
 namespace {
-struct EvalSlot { const float *buf; hipEvent_t scored, ranked; bool used; };
+struct EvalSlot { const float *buf; hipEvent_t scored, ranked; bool used; uint64_t last_use; };
 std::mutex g_eval_mu;
 std::vector<EvalSlot> g_eval_slots;
+uint64_t g_eval_clock = 0;
+constexpr size_t EVAL_SLOTS_MAX = 8;      // a caller alternates two (or a few) score buffers; older entries are recycled
 EvalSlot &eval_slot(const float *buf)
 {
+    ++g_eval_clock;
     for (auto &sl : g_eval_slots)
-        if (sl.buf == buf) return sl;
-    EvalSlot sl{buf, nullptr, nullptr, false};
+        if (sl.buf == buf) { sl.last_use = g_eval_clock; return sl; }
+    if (g_eval_slots.size() >= EVAL_SLOTS_MAX) {          // recycle the least recently used entry (its events are reused:
+        size_t lru = 0;                                   // a wait on the old `ranked` event is harmless, never wrong)
+        for (size_t i = 1; i < g_eval_slots.size(); ++i)
+            if (g_eval_slots[i].last_use < g_eval_slots[lru].last_use) lru = i;
+        g_eval_slots[lru].buf = buf;
+        g_eval_slots[lru].last_use = g_eval_clock;
+        return g_eval_slots[lru];
+    }
+    EvalSlot sl{buf, nullptr, nullptr, false, g_eval_clock};
     (void)hipEventCreateWithFlags(&sl.scored, hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&sl.ranked, hipEventDisableTiming);
     g_eval_slots.push_back(sl);
     return g_eval_slots.back();
 }
 }  // namespace
+extern "C" {
 
 int okge_evaluate_batch(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
                         const int64_t *filt_ptr, const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr,
@@ -838,6 +851,109 @@ int okge_evaluate_batch(const okge_tables *t, const okge_prefix_batch *batch, co
         sl.used = true;
     }
     return OKGE_OK;
+}
+
+// ---- fused evaluation: no (B, N) score block ------------------------------------------------------------------------
+namespace {
+struct EvalGeometry { size_t off_Q, off_true, off_filt, off_counts, total; bool slab; };
+constexpr size_t EVAL_SLAB_MAX = (size_t)256 << 20;      // per-tile count slabs up to 256 MB; beyond that: atomics
+bool eval_geometry(int B, int N, int d, int64_t n_groups, int64_t n_filter, Geometry &g, EvalGeometry &e)
+{
+    if (!make_geometry(B, N, d, g) || n_groups < 0 || n_filter < 0) return false;
+    size_t off = 0;
+    e.off_Q = off;      off += align_up((size_t)g.Bpad * g.ldq * sizeof(float), 256);
+    e.off_true = off;   off += align_up((size_t)std::max<int64_t>(n_groups, 1) * sizeof(float), 256);
+    e.off_filt = off;   off += align_up((size_t)std::max<int64_t>(n_filter, 1) * sizeof(float), 256);
+    const size_t slab_bytes = (size_t)g.tiles * std::max<int64_t>(n_groups, 1) * sizeof(uint32_t);
+    e.slab = slab_bytes <= EVAL_SLAB_MAX;
+    e.off_counts = off; off += align_up(e.slab ? slab_bytes : (size_t)std::max<int64_t>(n_groups, 1) * 2 * sizeof(int32_t), 256);
+    e.total = off;
+    return true;
+}
+}  // namespace
+
+size_t okge_eval_workspace_bytes(int32_t B, int32_t N, int32_t d, int64_t n_groups, int64_t n_filter)
+{
+    Geometry g;
+    EvalGeometry e;
+    return eval_geometry(B, N, d, n_groups, n_filter, g, e) ? e.total : 0;
+}
+
+// phases: 1 = point scores (+ queries), 2 = tile sweep, 4 = ranks + meters; okge_evaluate_fused runs all three on one
+// stream, okge_evaluate_fused_phase lets a caller put them on different streams (evaluate.FusedEvaluator: the two small
+// latency-bound kernels of neighbouring batches run beside the sweep)
+static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                               const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
+                               const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_common(t, batch, cand)) return rc;
+    if (!filt_ptr || !row_ptr || !grp_ptr || !ids || !ranks || !acc || n_groups < 0 || n_filter < 0 || (n_filter > 0 && !filt_col))
+        return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
+    if (t->d > 256) return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation covers slot sizes up to 256: use okge_evaluate_batch");
+    if (cand->table || cand->drop.p > 0.f || batch->drop_po_ent.p > 0.f || batch->drop_sp_ent.p > 0.f ||
+        batch->drop_po_rel.p > 0.f || batch->drop_sp_rel.p > 0.f)
+        return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation is the eval-mode path (no dropout, candidates from the entity table)");
+    if (n_groups == 0) return OKGE_OK;
+    const int32_t B = batch->n_po + batch->n_sp;
+    Geometry g;
+    EvalGeometry eg;
+    eval_geometry(B, cand->n, t->d, n_groups, n_filter, g, eg);
+    if (!workspace || workspace_bytes < eg.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    float *Q = reinterpret_cast<float *>(ws + eg.off_Q), *tru = reinterpret_cast<float *>(ws + eg.off_true);
+    float *fx = reinterpret_cast<float *>(ws + eg.off_filt);
+    int32_t *counts = reinterpret_cast<int32_t *>(ws + eg.off_counts);
+    hipError_t e = hipSuccess;
+    if (phases & 1) {
+        if (!eg.slab) {
+            e = hipMemsetAsync(counts, 0, (size_t)n_groups * 2 * sizeof(int32_t), st);
+            if (e != hipSuccess) return fail_hip(e, "clear rank counters");
+        }
+        const PrefixDev p = to_dev(*batch);
+        ScopedTimer tm("eval_points", st);
+        e = launch_eval_points(t->E, t->R, t->d, t->scorer, p, Q, g.ldq, g.Bpad, g.KB, cand->ids, cand->first_id, row_ptr, grp_ptr,
+                               ids, filt_ptr, filt_col, tru, fx, st);
+        if (e != hipSuccess) return fail_hip(e, "eval_points");
+    }
+    FusedArgs a;
+    fill_fused_common(a, g, t, cand, ws);
+    a.Q = Q;
+    a.rk_row_ptr = row_ptr; a.rk_true = tru; a.rk_ngroups = n_groups;
+    a.rk_counts = eg.slab ? nullptr : counts;
+    a.rk_slab = eg.slab ? reinterpret_cast<uint32_t *>(counts) : nullptr;
+    a.b_per_block = g.Bpad;
+    if (phases & 2) {
+        ScopedTimer tm("fused_tile_count", st);
+        e = launch_fused(MODE_COUNT, a, g.tiles, 1, st);
+        if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<count>");
+    }
+    if (phases & 4) {
+        ScopedTimer tm("eval_ranks", st);
+        e = launch_eval_ranks(a.rk_counts, a.rk_slab, g.tiles, tru, fx, filt_ptr, row_ptr, B, n_groups, ranks, acc, st);
+        if (e != hipSuccess) return fail_hip(e, "eval_ranks");
+    }
+    return OKGE_OK;
+}
+
+int okge_evaluate_fused(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                        const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
+                        const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
+                        void *workspace, size_t workspace_bytes, void *stream)
+{
+    return evaluate_fused_impl(7, t, batch, cand, filt_ptr, filt_col, n_filter, row_ptr, grp_ptr, ids, n_groups, ranks, acc,
+                               workspace, workspace_bytes, stream);
+}
+
+int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                              const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
+                              const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (phase != 1 && phase != 2 && phase != 4) return fail(OKGE_ERR_INVALID, "phase must be 1 (points), 2 (sweep) or 4 (ranks)");
+    return evaluate_fused_impl(phase, t, batch, cand, filt_ptr, filt_col, n_filter, row_ptr, grp_ptr, ids, n_groups, ranks, acc,
+                               workspace, workspace_bytes, stream);
 }
 
 int okge_group_true_scores(const float *scores, int64_t ld_scores, int32_t B, int32_t col0, int32_t n_local,

@@ -13,7 +13,7 @@ constexpr int LDG = 68;            // leading dimension of the 64x64 G / X tile 
 constexpr int FUSED_THREADS = 256; // 4 waves, one per SIMD
 constexpr int POS_CACHE = 512;     // positives of one candidate tile cached in LDS (more spill to global reads)
 
-enum { MODE_TRAIN_BCE = 0, MODE_SCORE = 1, MODE_STATS = 2, MODE_TRAIN_KL = 3 };
+enum { MODE_TRAIN_BCE = 0, MODE_SCORE = 1, MODE_STATS = 2, MODE_TRAIN_KL = 3, MODE_COUNT = 4 };
 enum { LOSS_BCE = 0, LOSS_KL = 1 };
 enum { SC_COMPLEX = 0, SC_DISTMULT = 1 };
 
@@ -31,6 +31,13 @@ struct FusedArgs {
     double        *loss_partial;
     float         *X;          // score mode
     float         *stats;      // stats mode: float2 [tiles][Bpad]
+    // count mode (fused evaluation): per answer group of every row, how many of the tile's scores are greater than /
+    // equal to the group's true score -> atomically added to rk_counts[group][2]
+    const int64_t *rk_row_ptr; // [B + 1] groups of each row
+    const float   *rk_true;    // [n_groups]
+    int32_t       *rk_counts;  // [n_groups][2]   (atomics; used when the slab would be too large)
+    uint32_t      *rk_slab;    // [tiles][n_groups] packed (#greater | #equal << 16) of every tile: plain coalesced stores
+    int64_t        rk_ngroups;
     unsigned long long *stamps_dbg;   // diagnostic build (-DOKGE_STAMPS) only
     int64_t        ldx;
     DropDev        drop_c;
@@ -102,6 +109,13 @@ hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_rank_metrics(const int64_t *ranks, int64_t n, double *acc, hipStream_t st);
+// fused evaluation (okge_evaluate_fused): point scores in the tile kernel's summation order, then ranks from the counts
+hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
+                              int KB, const int32_t *cand_ids, int cand_first, const int64_t *row_ptr, const int64_t *grp_ptr,
+                              const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col, float *true_out,
+                              float *filt_x, hipStream_t st);
+hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int tiles, const float *true_scores, const float *filt_x, const int64_t *filt_ptr,
+                             const int64_t *row_ptr, int B, int64_t n_groups, int64_t *ranks, double *acc, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, int col0, const float *true_in, float *true_out, int64_t *counts_out,

@@ -43,23 +43,12 @@ __device__ __forceinline__ void fold_complex(bool sp, float e1, float e2, float 
     q2 = sp ? __fadd_rn(c, dd) : __fsub_rn(c, dd);
 }
 
-__global__ __launch_bounds__(128) void encode_queries_kernel(const float *__restrict__ E, const float *__restrict__ R,
-                                                             int d, int scorer, const PrefixDev p,
-                                                             float *__restrict__ Q, int ldq, int Bpad,
-                                                             float *__restrict__ ent_rows,
-                                                             const int32_t *__restrict__ pos_col, int nnz,
-                                                             int32_t *__restrict__ tile_ptr, int tiles, int tile_w,
-                                                             int cand_col0)
+// One folded query row (and / or its masked entity row): gather + dropout + fold.  All threads of the workgroup take part.
+__device__ __forceinline__ void encode_query_row(const float *__restrict__ E, const float *__restrict__ R, int d, int scorer,
+                                                 const PrefixDev &p, int b, float *__restrict__ q, float *__restrict__ er,
+                                                 int ldq)
 {
-    if ((int)blockIdx.x >= Bpad) {
-        // extra workgroups: offsets of each candidate tile's positives in the column-sorted coordinate list
-        const int t = ((int)blockIdx.x - Bpad) * 128 + threadIdx.x;
-        if (t <= tiles) tile_ptr[t] = lower_bound_i32(pos_col, nnz, cand_col0 + t * tile_w);
-        return;
-    }
-    const int b = blockIdx.x, B = p.n_po + p.n_sp;
-    float *q = Q ? Q + (size_t)b * ldq : nullptr;         // Q == nullptr: only the masked entity rows are wanted
-    float *er = ent_rows ? ent_rows + (size_t)b * ldq : nullptr;
+    const int B = p.n_po + p.n_sp;
     RowSrc rs;
     rs.owned = false;
     if (b < B) rs = row_source(p, b);
@@ -92,6 +81,25 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
         if (q) q[k] = 0.f;
         if (er) er[k] = 0.f;
     }
+}
+
+__global__ __launch_bounds__(128) void encode_queries_kernel(const float *__restrict__ E, const float *__restrict__ R,
+                                                             int d, int scorer, const PrefixDev p,
+                                                             float *__restrict__ Q, int ldq, int Bpad,
+                                                             float *__restrict__ ent_rows,
+                                                             const int32_t *__restrict__ pos_col, int nnz,
+                                                             int32_t *__restrict__ tile_ptr, int tiles, int tile_w,
+                                                             int cand_col0)
+{
+    if ((int)blockIdx.x >= Bpad) {
+        // extra workgroups: offsets of each candidate tile's positives in the column-sorted coordinate list
+        const int t = ((int)blockIdx.x - Bpad) * 128 + threadIdx.x;
+        if (t <= tiles) tile_ptr[t] = lower_bound_i32(pos_col, nnz, cand_col0 + t * tile_w);
+        return;
+    }
+    const int b = blockIdx.x;
+    encode_query_row(E, R, d, scorer, p, b, Q ? Q + (size_t)b * ldq : nullptr,      // Q == nullptr: only the masked
+                     ent_rows ? ent_rows + (size_t)b * ldq : nullptr, ldq);         // entity rows are wanted
 }
 
 // Q[b] = fold(masked entity row b, dropout(R[rel_b])) from ALREADY MASKED entity rows (sharded path: the rows arrive
@@ -731,6 +739,120 @@ __global__ __launch_bounds__(256) void score_triples_kernel(const float *__restr
     if (lane == 0) out[i] = acc;
 }
 
+// ---- fused evaluation (okge_evaluate_fused) ----------------------------------------------------------------------
+// score(b, n) exactly as fused_tile_kernel<KB, MODE_SCORE/MODE_COUNT> computes it: v_mfma_f32_16x16x4_f32 is a
+// k-ordered fp32 fma chain (MI355X guide), and the tile kernel feeds it k = 16r + 4s + j in the order r, j, s -- so a
+// scalar fmaf chain in that order gives the same bits.  Columns >= d hold zeros on both sides: fma(0, 0, acc) == acc.
+__device__ __forceinline__ float point_score(const float *__restrict__ q /* LDS, zero padded to 16*KB */,
+                                             const float *__restrict__ row, int d, int KB, bool vec_ok)
+{
+    float acc = 0.f;
+    for (int r = 0; r < KB; ++r) {
+        float cv[16];
+        if (vec_ok && 16 * r + 16 <= d) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + 16 * r + 4 * m);
+                cv[4 * m] = v.x; cv[4 * m + 1] = v.y; cv[4 * m + 2] = v.z; cv[4 * m + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) cv[m] = 16 * r + m < d ? row[16 * r + m] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) acc = __fmaf_rn(q[16 * r + 4 * sl + j], cv[4 * sl + j], acc);
+    }
+    return acc;
+}
+
+// One workgroup per batch row: the folded query row (-> Q for the tile sweep, and LDS), then the POINT scores the rank
+// rule needs besides the sweep's counts: each answer group's true score = max over its ids (dataset.py:436), and the
+// score under every filter entry (they are replaced by -1e8, dataset.py:441: corrected in eval_ranks_kernel).
+__global__ __launch_bounds__(256) void eval_points_kernel(const float *__restrict__ E, const float *__restrict__ R, int d,
+                                                          int scorer, const PrefixDev p, float *__restrict__ Q, int ldq,
+                                                          int KB, const int32_t *__restrict__ cand_ids, int cand_first,
+                                                          const int64_t *__restrict__ row_ptr,
+                                                          const int64_t *__restrict__ grp_ptr,
+                                                          const int32_t *__restrict__ ids,
+                                                          const int64_t *__restrict__ filt_ptr,
+                                                          const int32_t *__restrict__ filt_col,
+                                                          float *__restrict__ true_out, float *__restrict__ filt_x)
+{
+    __shared__ float qs[512];
+    const int b = blockIdx.x, B = p.n_po + p.n_sp;
+    encode_query_row(E, R, d, scorer, p, b, qs, nullptr, 16 * KB);
+    __syncthreads();            // the row was written column-strided by other threads
+    for (int k = threadIdx.x; k < ldq; k += blockDim.x) Q[(size_t)b * ldq + k] = k < 16 * KB ? qs[k] : 0.f;
+    if (b >= B) return;
+    const bool vec_ok = (d & 3) == 0;
+    auto cand_row = [&](int col) {
+        const int64_t cid = cand_ids ? (int64_t)cand_ids[col] : (int64_t)cand_first + col;
+        return E + cid * d;
+    };
+    const int64_t g_lo = row_ptr[b], g_hi = row_ptr[b + 1];
+    for (int64_t g = g_lo + threadIdx.x; g < g_hi; g += blockDim.x) {
+        float t = -INFINITY;
+        for (int64_t j = grp_ptr[g]; j < grp_ptr[g + 1]; ++j) t = fmaxf(t, point_score(qs, cand_row(ids[j]), d, KB, vec_ok));
+        true_out[g] = t;
+    }
+    const int64_t f_lo = filt_ptr[b], f_hi = filt_ptr[b + 1];
+    for (int64_t f = f_lo + threadIdx.x; f < f_hi; f += blockDim.x) filt_x[f] = point_score(qs, cand_row(filt_col[f]), d, KB, vec_ok);
+}
+
+// One wave per answer group: rank = #greater + #equal / 2 from the sweep's counts, after replacing the scores under the
+// row's filter entries by -1e8 (dataset.py:441-446); then the meters of compute_metrics (dataset.py:447-452) are added
+// to acc[7] (double atomics: a handful per workgroup).
+__global__ __launch_bounds__(256) void eval_ranks_kernel(const int32_t *__restrict__ counts, const uint32_t *__restrict__ slab,
+                                                         int tiles, const float *__restrict__ true_scores,
+                                                         const float *__restrict__ filt_x, const int64_t *__restrict__ filt_ptr,
+                                                         const int64_t *__restrict__ row_ptr, int B, int64_t n_groups,
+                                                         int64_t *__restrict__ ranks, double *__restrict__ acc)
+{
+    __shared__ double red[4][7];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 4 + w;
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (g < n_groups) {
+        int lo = 0, hi = B;                              // the row that owns group g: row_ptr[row] <= g < row_ptr[row + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (row_ptr[mid] <= g) lo = mid; else hi = mid;
+        }
+        const float t = true_scores[g];
+        int gt = 0, eq = 0;
+        for (int64_t f = filt_ptr[lo] + lane; f < filt_ptr[lo + 1]; f += 64) {
+            const float x = filt_x[f];
+            gt += (-1e8f > t) - (x > t);
+            eq += (-1e8f == t) - (x == t);
+        }
+        if (slab)                                        // the sweep's per-tile packed counts of this group
+            for (int tl = lane; tl < tiles; tl += 64) {
+                const uint32_t pk = slab[(size_t)tl * n_groups + g];
+                gt += (int)(pk & 0xFFFFu);
+                eq += (int)(pk >> 16);
+            }
+        gt = wave_sum(gt);
+        eq = wave_sum(eq);
+        if (lane == 0) {
+            const int64_t r = (int64_t)(slab ? 0 : counts[2 * g]) + gt + ((int64_t)(slab ? 0 : counts[2 * g + 1]) + eq) / 2;
+            ranks[g] = r;
+            v[0] = 1.0;
+            v[1] = (double)(1.0f / (float)(r + 1));       // fp32 reciprocal like the reference's (1/(rank+1).float())
+            v[2] = (double)r;
+            v[3] = r < 1; v[4] = r < 3; v[5] = r < 10; v[6] = r < 50;
+        }
+    }
+    if (lane == 0)
+        for (int k = 0; k < 7; ++k) red[w][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const double tsum = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (tsum != 0.0) atomicAdd(acc + threadIdx.x, tsum);
+    }
+}
+
 // ---- launchers -----------------------------------------------------------------------------------------
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st)
@@ -875,6 +997,31 @@ hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int
     if (B <= 0) return hipSuccess;
     hipLaunchKernelGGL(ranks_kernel, dim3(B, 4), dim3(256), 0, st, scores, ld, N, filt_ptr, filt_col, row_ptr, grp_ptr,
                        ids, ranks, col0, true_in, true_out, counts_out);
+    return hipGetLastError();
+}
+
+}  // namespace okge
+
+namespace okge {
+
+hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
+                              int KB, const int32_t *cand_ids, int cand_first, const int64_t *row_ptr, const int64_t *grp_ptr,
+                              const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col, float *true_out,
+                              float *filt_x, hipStream_t st)
+{
+    if (Bpad <= 0) return hipSuccess;
+    hipLaunchKernelGGL(eval_points_kernel, dim3(Bpad), dim3(256), 0, st, E, R, d, scorer, p, Q, ldq, KB, cand_ids, cand_first,
+                       row_ptr, grp_ptr, ids, filt_ptr, filt_col, true_out, filt_x);
+    return hipGetLastError();
+}
+
+hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int tiles, const float *true_scores, const float *filt_x,
+                             const int64_t *filt_ptr, const int64_t *row_ptr, int B, int64_t n_groups, int64_t *ranks, double *acc,
+                             hipStream_t st)
+{
+    if (n_groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(eval_ranks_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, st, counts, slab, tiles, true_scores, filt_x,
+                       filt_ptr, row_ptr, B, n_groups, ranks, acc);
     return hipGetLastError();
 }
 

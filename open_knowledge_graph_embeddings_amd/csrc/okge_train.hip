@@ -1,10 +1,12 @@
 // Prefix-scoring kernels for gfx950 (MI355X), 64x64 cut.
 //
-//   fused_tile_kernel<KB, MODE>   MODE_SCORE | MODE_STATS
+//   fused_tile_kernel<KB, MODE>   MODE_SCORE | MODE_STATS | MODE_COUNT
 //     One workgroup owns a tile of NT=64 candidate entities (gathered + dropped-out once into LDS) and sweeps the
 //     batch's folded query rows in chunks of BC=64:  X = Q_chunk . C_tile^T  (v_mfma_f32_16x16x4_f32, exact fp32).
 //     MODE_SCORE writes X (evaluation / *_prefix_score: openkge/model.py:52-74,198-229,268-274);
 //     MODE_STATS writes per-row (max, sum-exp) partials for the KL loss' log_softmax (openkge/trainer.py:99-100).
+//     MODE_COUNT (fused evaluation) compares X in registers with each row's true answer scores and adds the tile's
+//     {#greater, #equal} to per-group counters: the rank rule of dataset.py:436-446 without the (B, N) score block.
 //     The training step (score -> loss -> dCand) is fused_tile32_kernel in okge_train32.hip.
 //
 //   dq_kernel<KB>
@@ -178,11 +180,42 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
     load_cand_tile<KB>(Cs, nullptr, nullptr, a.E, d, a.cand_ids, a.cand_first, a.N, n0, a.drop_c, vec_ok, tid,
                        a.cand_col0);
 
+    // MODE_COUNT: the group range of the lane's row is loaded ONE CHUNK AHEAD and the row's first RK_PRE true scores before
+    // the score product, so that the counting loop does not wait on dependent global loads (one workgroup of four
+    // waves per CU: nothing else would hide them)
+    constexpr int RK_PRE = 4;
+    int64_t rk_glo = 0, rk_glo_n = 0, rk_c0 = 0, rk_c1 = 0, rk_c0_n = 0, rk_c1_n = 0;
+    int rk_ng = 0, rk_ng_n = 0;
+    float rk_t[RK_PRE];
+    auto rk_fetch_rows = [&](int b0) {
+        if (MODE != MODE_COUNT) return;
+        const int b = b0 + 16 * w + c;
+        rk_glo_n = 0; rk_ng_n = 0;
+        if (b < b_end) {
+            rk_glo_n = a.rk_row_ptr[b];
+            rk_ng_n = (int)(a.rk_row_ptr[b + 1] - rk_glo_n);
+        }
+        rk_c0_n = a.rk_row_ptr[min(b0, a.B)];
+        rk_c1_n = a.rk_row_ptr[min(b0 + BC, a.B)];
+    };
+    rk_fetch_rows(b_begin);
+
     for (int b0 = b_begin; b0 < b_end; b0 += BC) {
         // ---- phase A: park the prefetched chunk in LDS, prefetch the next chunk -------------------------------
 #pragma unroll
         for (int it = 0; it < KB; ++it) *reinterpret_cast<v4f *>(Qs + qr * LDK + 4 * qq + 16 * it) = qreg[it];
         if (b0 + BC < b_end) fetch_chunk(b0 + BC);
+        if (MODE == MODE_COUNT) {
+            rk_glo = rk_glo_n; rk_ng = rk_ng_n;
+#pragma unroll
+            for (int jj = 0; jj < RK_PRE; ++jj)
+                rk_t[jj] = jj < rk_ng ? a.rk_true[rk_glo + jj] : __builtin_nanf("");      // NaN never compares true
+            rk_c0 = rk_c0_n; rk_c1 = rk_c1_n;
+            if (b0 + BC < b_end) rk_fetch_rows(b0 + BC);
+            // the chunk's packed counters live in LDS (the X staging tile is free in this mode)
+            if (a.rk_slab && rk_c1 - rk_c0 <= BC * LDG)
+                for (int k = tid; k < (int)(rk_c1 - rk_c0); k += FUSED_THREADS) reinterpret_cast<uint32_t *>(Xs)[k] = 0u;
+        }
         __syncthreads();
 
         // ---- phase B: X = Q_chunk . C^T ; wave w owns rows 16w..16w+15, all four 16-wide n blocks -------------
@@ -208,7 +241,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) x[nb] = mfma16(av[j], bv[nb][j], x[nb]);
+                    for (int nb = 0; nb < 4; ++nb)
+                        x[nb] = MODE == MODE_COUNT ? mfma16(bv[nb][j], av[j], x[nb])     // X^T block: lane = batch row
+                                                   : mfma16(av[j], bv[nb][j], x[nb]);
                 av = an;
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) bv[nb] = bn[nb];
@@ -217,6 +252,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
             }
         }
         // lane holds X[b = b0 + 16w + 4s + i][n = n0 + 16nb + c] in x[nb][i]
+        // (MODE_COUNT, operands swapped: X[b = b0 + 16w + c][n = n0 + 16nb + 4s + i] -- the same products in the same
+        //  order, a * b == b * a, so the same bits -- one batch row per lane)
 
         if (MODE == MODE_SCORE) {
 #pragma unroll
@@ -240,6 +277,66 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
                 }
             }
             __syncthreads();
+        } else if (MODE == MODE_COUNT) {
+            // fused evaluation: compare the block against the true scores of each row's answer groups and add the
+            // {#greater, #equal} of this tile to the group's counters; the (B, N) score block is never written.
+            // (dataset.py:436-446; the filter correction is applied by eval_ranks_kernel from point scores.)
+            // The groups of a chunk's 64 rows are one contiguous index range: their packed counts (#greater | #equal << 16)
+            // are summed in LDS and leave as one coalesced store per tile and chunk.  (Global atomics from a few lanes
+            // per instruction cost ~100 cycles each and made this sweep 3.5x slower; with the untransposed block, 4 rows
+            // x 4 candidates per lane, the per-group compare / cross-lane sum cost 3x the instructions per element.)
+            uint32_t *cnt = reinterpret_cast<uint32_t *>(Xs);
+            constexpr int CNT_CAP = BC * LDG;
+            const int64_t gc_lo = rk_c0, gc_hi = rk_c1;
+            const bool in_lds = a.rk_slab && gc_hi - gc_lo <= CNT_CAP;
+            uint32_t *slab_row = a.rk_slab ? a.rk_slab + (size_t)blockIdx.x * a.rk_ngroups : nullptr;
+            float xm[4][4];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xm[nb][i] = n0 + 16 * nb + 4 * s + i < a.N ? x[nb][i] : -INFINITY;
+            const int64_t g_lo = rk_glo;
+            const int ng = rk_ng;
+            for (int j = 0; __builtin_amdgcn_ballot_w64(j < ng) != 0; ++j) {
+                float t = j < ng && j >= RK_PRE ? a.rk_true[g_lo + j] : __builtin_nanf("");
+#pragma unroll
+                for (int jj = 0; jj < RK_PRE; ++jj) t = j == jj ? rk_t[jj] : t;
+                int pq[4] = {0, 0, 0, 0};                    // four independent chains: one wave per SIMD, nothing else
+                float mx = -INFINITY;                        // hides the compare -> add latency
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pq[nb] += xm[nb][i] > t;
+                        mx = fmaxf(mx, xm[nb][i] <= t ? xm[nb][i] : -INFINITY);      // largest score not above t
+                    }
+                int pk = (pq[0] + pq[1]) + (pq[2] + pq[3]);
+                const bool any_eq = mx == t;
+                if (__builtin_amdgcn_ballot_w64(any_eq) != 0) {          // exact ties are rare (the true answer's own tile)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) pk += xm[nb][i] == t ? 65536 : 0;
+                }
+                if (j < ng) {        // the row's 64 candidates of this tile sit in the four lanes c, c+16, c+32, c+48
+                    if (in_lds) {
+                        if (pk) atomicAdd(&cnt[g_lo + j - gc_lo], (uint32_t)pk);
+                    } else {
+                        pk += __shfl_xor(pk, 16);
+                        pk += __shfl_xor(pk, 32);
+                        if (s == 0) {
+                            if (slab_row) slab_row[g_lo + j] = (uint32_t)pk;
+                            else {
+                                if (pk & 0xFFFF) atomicAdd(a.rk_counts + 2 * (g_lo + j), pk & 0xFFFF);
+                                if (pk >> 16) atomicAdd(a.rk_counts + 2 * (g_lo + j) + 1, pk >> 16);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (in_lds)
+                for (int k = tid; k < (int)(gc_hi - gc_lo); k += FUSED_THREADS) slab_row[gc_lo + k] = cnt[k];
         } else {
             // MODE_STATS: per row of the chunk, max and sum-exp over this tile's candidates
 #pragma unroll
@@ -397,6 +494,7 @@ static hipError_t launch_fused_m(int mode, const FusedArgs &a, dim3 grid, size_t
     switch (mode) {
         case MODE_SCORE: return launch_fused_t<KB, MODE_SCORE>(a, grid, shmem, st);
         case MODE_STATS: return launch_fused_t<KB, MODE_STATS>(a, grid, shmem, st);
+        case MODE_COUNT: return launch_fused_t<KB, MODE_COUNT>(a, grid, shmem, st);
         default:         return hipErrorInvalidValue;      // training: fused_tile32_kernel
     }
 }

@@ -13,6 +13,95 @@ from . import hotpath as H
 from .metrics import MetricResult
 
 
+def _meters(a):
+    n = int(a[0])
+    out = MetricResult()
+    if n:
+        out["mrr"].update(a[1] / n, n)
+        out["mr"].update(a[2] / n, n)
+        for k, v in (("h1", a[3]), ("h3", a[4]), ("h10", a[5]), ("h50", a[6])):
+            out[k].update(v / n, n)
+    return out, n
+
+
+class FusedEvaluator:
+    """The evaluation loop on okge_evaluate_fused: per batch three launches (point scores, tile sweep with in-register
+    counting, ranks + meters), no (B, N) score block, no host read until the end.  The sweep runs on the current
+    stream; the two small latency-bound kernels run on a side stream, software-pipelined so that batch i+1's point
+    scores and batch i-1's ranks execute beside batch i's sweep (two workspaces / rank buffers alternate).  Slot sizes
+    up to 256, eval mode; PipelinedEvaluator (materialised scores) covers the rest."""
+
+    def __init__(self, E, R, scorer, engine=None):
+        self.E, self.R, self.scorer = E, R, scorer
+        self.device = E.device
+        self.engine = engine or H.HotPath(self.device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self._ws = [None, None]
+        self._ranks = [None, None]
+        self._t = self.engine._tables(E, R, scorer)
+
+    def _args(self, cb, slot, acc):
+        eng, b = self.engine, cb.batch
+        pb, c, keep = eng._batch(b)
+        n_groups, n_filter = int(cb.grp_ptr.numel()) - 1, int(cb.filt_col.numel())
+        need = int(eng.lib.okge_eval_workspace_bytes(b.B, c.n, self._t.d, n_groups, n_filter))
+        if self._ws[slot] is None or self._ws[slot].numel() < need:
+            self.side.synchronize()
+            self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[slot].record_stream(self.side)
+        if self._ranks[slot] is None or self._ranks[slot].numel() < n_groups:
+            self.side.synchronize()
+            self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
+            self._ranks[slot].record_stream(self.side)
+        for x in (cb.filt_ptr, cb.filt_col, cb.row_ptr, cb.grp_ptr, cb.ids, b.po_rel, b.po_obj, b.sp_subj, b.sp_rel, b.cand_ids):
+            if x is not None:
+                x.record_stream(self.side)
+        return (ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c), cb.filt_ptr.data_ptr(),
+                cb.filt_col.data_ptr() if n_filter else None, n_filter, cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(),
+                cb.ids.data_ptr(), n_groups, self._ranks[slot].data_ptr(), acc.data_ptr(), self._ws[slot].data_ptr(),
+                self._ws[slot].numel()), (pb, c, keep)
+
+    def run(self, batches):
+        """batches: iterable of dataset.CollatedBatch built with is_training_data=False -> (MetricResult, #groups)"""
+        lib = self.engine.lib
+        acc = torch.zeros(7, dtype=torch.float64, device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        side_h, main_h = ctypes.c_void_p(self.side.cuda_stream), ctypes.c_void_p(main.cuda_stream)
+        self.side.wait_stream(main)                         # tables / batches were produced on the current stream
+        it = iter(batches)
+        cur = next(it, None)
+        i, keep_alive = 0, []
+        if cur is None:
+            return _meters(acc.cpu().tolist())
+        cur_args, ka = self._args(cur, 0, acc)
+        keep_alive.append(ka)
+        N.check(lib.okge_evaluate_fused_phase(1, *cur_args, side_h), "okge_evaluate_fused_phase(points)")
+        pts = torch.cuda.Event()
+        pts.record(self.side)
+        while cur is not None:
+            main.wait_event(pts)
+            N.check(lib.okge_evaluate_fused_phase(2, *cur_args, main_h), "okge_evaluate_fused_phase(sweep)")
+            swept = torch.cuda.Event()
+            swept.record(main)
+            nxt = next(it, None)
+            if nxt is not None:                              # next batch's point scores go in BEFORE this batch's ranks
+                nxt_args, ka = self._args(nxt, (i + 1) & 1, acc)
+                keep_alive.append(ka)
+                N.check(lib.okge_evaluate_fused_phase(1, *nxt_args, side_h), "okge_evaluate_fused_phase(points)")
+                pts = torch.cuda.Event()
+                pts.record(self.side)
+            self.side.wait_event(swept)
+            N.check(lib.okge_evaluate_fused_phase(4, *cur_args, side_h), "okge_evaluate_fused_phase(ranks)")
+            cur, cur_args = nxt, (nxt_args if nxt is not None else None)
+            i += 1
+            if len(keep_alive) > 4:
+                keep_alive.pop(0)
+        main.wait_stream(self.side)
+        out = _meters(acc.cpu().tolist())
+        del keep_alive
+        return out
+
+
 class PipelinedEvaluator:
     def __init__(self, E, R, scorer, engine=None):
         self.E, self.R, self.scorer = E, R, scorer
@@ -28,10 +117,17 @@ class PipelinedEvaluator:
         self._rs = ctypes.c_void_p(self.rank_stream.cuda_stream)
 
     def _buffer(self, slot, B, n):
+        """score buffer of a slot: grown (never shrunk) to the largest B x ld seen, and only after the rank stream has
+        drained -- the ranks kernel of an earlier batch may still be reading the old one -- so a slot keeps ONE
+        pointer for the library's per-buffer events; the rank stream is recorded as a user of the allocation"""
         ld = (n + 3) // 4 * 4
         buf = self._bufs[slot]
-        if buf is None or buf.shape[0] < B or buf.shape[1] != ld:
-            buf = self._bufs[slot] = torch.empty((B, ld), dtype=torch.float32, device=self.device)
+        if buf is None or buf.shape[0] < B or buf.shape[1] < ld:
+            self.rank_stream.synchronize()
+            rows = max(B, 0 if buf is None else buf.shape[0])
+            cols = max(ld, 0 if buf is None else buf.shape[1])
+            buf = self._bufs[slot] = torch.empty((rows, cols), dtype=torch.float32, device=self.device)
+            buf.record_stream(self.rank_stream)
         return buf[:B, :n]
 
     def run(self, batches):
@@ -46,7 +142,9 @@ class PipelinedEvaluator:
             x = self._buffer(slot, cb.batch.B, cb.n_cand)
             n_groups = int(cb.grp_ptr.numel()) - 1
             if self._ranks[slot] is None or self._ranks[slot].numel() < n_groups:
+                self.rank_stream.synchronize()
                 self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
+                self._ranks[slot].record_stream(self.rank_stream)
             for t in (cb.filt_ptr, cb.filt_col, cb.row_ptr, cb.grp_ptr, cb.ids):
                 t.record_stream(self.rank_stream)                # read there after `cb` may have gone out of scope here
             # one library call: scores on the current stream, ranks + meters on rank_stream, ordered by library events;
@@ -67,11 +165,4 @@ class PipelinedEvaluator:
         main.wait_stream(self.rank_stream)
         a = acc.cpu().tolist()
         del keep
-        n = int(a[0])
-        out = MetricResult()
-        if n:
-            out["mrr"].update(a[1] / n, n)
-            out["mr"].update(a[2] / n, n)
-            for k, v in (("h1", a[3]), ("h3", a[4]), ("h10", a[5]), ("h50", a[6])):
-                out[k].update(v / n, n)
-        return out, n
+        return _meters(a)

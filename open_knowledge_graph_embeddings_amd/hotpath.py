@@ -425,6 +425,28 @@ class HotPath:
                                              ctypes.c_void_p(rank_stream.cuda_stream)), "okge_evaluate_batch")
         del keep
 
+    def evaluate_fused(self, E, R, scorer, batch: PrefixBatch, filt_ptr, filt_col, row_ptr, grp_ptr, ids, ranks=None, acc=None):
+        """filtered ranks + meters of one evaluation batch without the (B, N) score block (okge_evaluate_fused): ranks
+        (int64 per answer group, bit-equal to score() + filtered_ranks()) and acc (7 device doubles, accumulated)."""
+        pb, c, keep = self._batch(batch)
+        t = self._tables(E, R, scorer)
+        n_groups, n_filter = int(grp_ptr.numel()) - 1, int(filt_col.numel())
+        need = int(self.lib.okge_eval_workspace_bytes(batch.B, c.n, t.d, n_groups, n_filter))
+        if need > self._ws_bytes:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        if ranks is None:
+            ranks = torch.empty(max(n_groups, 1), dtype=torch.int64, device=self.device)
+        if acc is None:
+            acc = torch.zeros(7, dtype=torch.float64, device=self.device)
+        N.check(self.lib.okge_evaluate_fused(ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), filt_ptr.data_ptr(),
+                                             _ptr(filt_col) if n_filter else None, n_filter, row_ptr.data_ptr(),
+                                             grp_ptr.data_ptr(), ids.data_ptr(), n_groups, ranks.data_ptr(), acc.data_ptr(),
+                                             self._ws.data_ptr(), self._ws_bytes, self._stream()), "okge_evaluate_fused")
+        del keep
+        return ranks[:n_groups], acc
+
     def rank_metrics(self, ranks, acc):
         """acc (7 device doubles) += {n, sum 1/(r+1), sum r, #r<1, #r<3, #r<10, #r<50}"""
         N.check(self.lib.okge_rank_metrics(ranks.data_ptr(), int(ranks.numel()), acc.data_ptr(), self._stream()),

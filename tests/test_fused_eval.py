@@ -1,0 +1,141 @@
+"""Fused evaluation (okge_evaluate_fused: point scores + tile sweep with in-register counting + ranks, no (B, N) score
+block) against the materialising path (okge_score_prefixes + okge_filtered_ranks) and the oracle's rank rule
+(openkge/dataset.py:423-453).  The bar: ranks BIT-EQUAL -- the point scores reproduce the tile kernel's fp32 summation
+order exactly, so not even a near-tie may move -- and the same meters."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import kge_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t if dt is None else t.to(dt)).cuda()
+
+
+def _case(rng, n_ent, n_rel, d, n_po, n_sp, scorer, max_groups, ties, cand_list=False, many=None):
+    """random tables / prefixes, answer groups (multi-id groups, rows without groups, one row with `many` groups) and an
+    all-splits filter; `ties`: tables from a tiny alphabet so that many scores are exactly equal"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    if ties:
+        E = rng.integers(-1, 2, (n_ent, d)).astype(np.float32) * 0.5
+        R = rng.integers(-1, 2, (n_rel, d)).astype(np.float32) * 0.5
+    else:
+        E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+        R = (rng.standard_normal((n_rel, d)) * 0.3).astype(np.float32)
+    batch = H.PrefixBatch()
+    if n_po:
+        batch.po_rel, batch.po_obj = _dev(rng.integers(2, n_rel, n_po).astype(np.int32)), _dev(rng.integers(2, n_ent, n_po).astype(np.int32))
+    if n_sp:
+        batch.sp_subj, batch.sp_rel = _dev(rng.integers(2, n_ent, n_sp).astype(np.int32)), _dev(rng.integers(2, n_rel, n_sp).astype(np.int32))
+    if cand_list:
+        cand = rng.permutation(np.arange(2, n_ent))[:max(8, (n_ent - 2) // 3)].astype(np.int32)
+        batch.cand_ids, N = _dev(cand), len(cand)
+    else:
+        batch.cand_first, batch.n_cand, N = 2, n_ent - 2, n_ent - 2
+    B = n_po + n_sp
+    row_ptr, grp_ptr, ids, filt_ptr, filt_col = [0], [0], [], [0], []
+    for b in range(B):
+        ng = 0 if rng.random() < 0.1 else int(rng.integers(1, max_groups + 1))
+        if many is not None and b == B // 2:
+            ng = many
+        row_ids = []
+        for _ in range(ng):
+            g = rng.integers(0, N, int(rng.integers(1, 4))).tolist()
+            ids.extend(g)
+            row_ids.extend(g)
+            grp_ptr.append(len(ids))
+        row_ptr.append(len(grp_ptr) - 1)
+        nf = int(rng.integers(0, 12)) if b != B // 3 else 300
+        f = np.unique(np.concatenate([rng.integers(0, N, nf), np.asarray(row_ids, np.int64)])).astype(np.int64) if (nf or row_ids) else np.zeros(0, np.int64)
+        if rng.random() < 0.2:
+            f = f[: len(f) // 2]                  # not every answer is filtered (the reference filters what it is given)
+        filt_col.extend(f.tolist())
+        filt_ptr.append(len(filt_col))
+    csr = dict(filt_ptr=np.asarray(filt_ptr, np.int64), filt_col=np.asarray(filt_col, np.int32), row_ptr=np.asarray(row_ptr, np.int64),
+               grp_ptr=np.asarray(grp_ptr, np.int64), ids=np.asarray(ids, np.int32))
+    return E, R, batch, csr, N
+
+
+def _check(hp, E, R, scorer, batch, csr, N):
+    Et, Rt = _dev(E), _dev(R)
+    d = {k: _dev(v) for k, v in csr.items()}
+    if d["filt_col"].numel() == 0:
+        d["filt_col"] = torch.zeros(1, dtype=torch.int32, device="cuda")[:0]
+    x = hp.score(Et, Rt, scorer, batch)
+    ref = hp.filtered_ranks(x.contiguous(), d["filt_ptr"], d["filt_col"] if d["filt_col"].numel() else torch.zeros(1, dtype=torch.int32, device="cuda"),
+                            d["row_ptr"], d["grp_ptr"], d["ids"]).cpu().numpy()
+    acc_ref = torch.zeros(7, dtype=torch.float64, device="cuda")
+    n_groups = len(csr["grp_ptr"]) - 1
+    if n_groups:
+        hp.rank_metrics(torch.from_numpy(ref).cuda(), acc_ref)
+    ranks, acc = hp.evaluate_fused(Et, Rt, scorer, batch, d["filt_ptr"], d["filt_col"], d["row_ptr"], d["grp_ptr"], d["ids"])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ranks.cpu().numpy(), ref)
+    np.testing.assert_allclose(acc.cpu().numpy(), acc_ref.cpu().numpy(), rtol=1e-12, atol=0)
+    # and the oracle's rule on the same scores
+    filt = np.zeros((batch.B, N), bool)
+    for b in range(batch.B):
+        filt[b, csr["filt_col"][csr["filt_ptr"][b]:csr["filt_ptr"][b + 1]]] = True
+    np.testing.assert_array_equal(ref, ko.filtered_ranks(x.cpu().numpy(), filt, csr["row_ptr"], csr["grp_ptr"], csr["ids"]))
+    return ranks
+
+
+@pytest.mark.parametrize("i", range(16))
+def test_fused_eval_random(okge_lib, i):
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    hp = H.HotPath("cuda:0")
+    rng = np.random.default_rng(1000 + i)
+    scorer = "complex" if i % 2 == 0 else "distmult"
+    d = [200, 64, 256, 24, 130, 208, 16, 100][i % 8]
+    if scorer == "complex" and d % 2:
+        d += 1
+    n_ent = [700, 130, 3000, 67, 1500, 515, 66, 2050][i % 8]
+    n_po, n_sp = [(40, 40), (0, 70), (100, 0), (13, 9), (64, 64), (1, 0), (33, 31), (130, 65)][i % 8]
+    E, R, batch, csr, N = _case(rng, n_ent, 30, d, n_po, n_sp, scorer, max_groups=[2, 6, 1, 3][i % 4], ties=i % 3 == 0,
+                                cand_list=i % 5 == 1, many=70 if i % 4 == 2 else None)
+    _check(hp, E, R, scorer, batch, csr, N)
+
+
+def test_fused_eval_fb15k237_batch(okge_lib):
+    """the real FB15k-237 evaluation batch G10 at the BASELINE size, against the reference's own ranks"""
+    from test_fb15k237_batch import check_ranks, tables
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    z = golden("g10_fb15k237_batch")
+    _, E, R = tables(z)
+    hp = H.HotPath("cuda:0")
+    N = E.shape[0] - 2
+    batch = H.PrefixBatch(po_rel=_dev(z["po_rel"].reshape(-1)), po_obj=_dev(z["po_obj"].reshape(-1)),
+                          sp_subj=_dev(z["sp_subj"].reshape(-1)), sp_rel=_dev(z["sp_rel"].reshape(-1)), cand_first=2, n_cand=N)
+    f = z["filter"]
+    csr = dict(filt_ptr=np.concatenate([[0], np.cumsum(np.bincount(f[:, 0], minlength=512))]).astype(np.int64),
+               filt_col=f[:, 1].astype(np.int32), row_ptr=z["row_ptr"], grp_ptr=z["grp_ptr"], ids=z["ids"])
+    ranks = _check(hp, E, R, "complex", batch, csr, N)
+    check_ranks(ranks.cpu().numpy(), z)
+
+
+def test_fused_evaluator_equals_pipelined(okge_lib):
+    """evaluate.FusedEvaluator over several batches of different shapes == evaluate.PipelinedEvaluator"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.dataset import CollatedBatch
+    from open_knowledge_graph_embeddings_amd.evaluate import FusedEvaluator, PipelinedEvaluator
+    rng = np.random.default_rng(5)
+    n_ent, d = 900, 200
+    E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal((20, d)) * 0.3).astype(np.float32)
+    cbs = []
+    for k in range(5):
+        _, _, batch, csr, N = _case(rng, n_ent, 20, d, 30 + 7 * k, 20 + 3 * k, "complex", 3, False, cand_list=k == 2)
+        dd = {kk: _dev(v) for kk, v in csr.items()}
+        cbs.append(CollatedBatch(batch, 1.0, 1.0, N, row_ptr=dd["row_ptr"], grp_ptr=dd["grp_ptr"], ids=dd["ids"],
+                                 filt_ptr=dd["filt_ptr"], filt_col=dd["filt_col"]))
+    Et, Rt = _dev(E), _dev(R)
+    a, na = FusedEvaluator(Et, Rt, "complex").run(cbs)
+    b, nb = PipelinedEvaluator(Et, Rt, "complex").run(cbs)
+    assert na == nb and na > 0
+    for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
+        assert abs(a[k].avg - b[k].avg) <= 1e-12 * max(1.0, abs(b[k].avg)), k
