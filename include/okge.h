@@ -413,6 +413,25 @@ int okge_rank_counts(const float *scores, int64_t ld_scores, int32_t B, int32_t 
                      const int64_t *filt_ptr, const int32_t *filt_col, const int64_t *row_ptr,
                      const float *true_scores, int64_t *counts, void *stream);
 
+/* ---- id safety ----------------------------------------------------------------------------------------
+ * Ids live in device memory; the kernels check every row index they form from one against its table, substitute row 0
+ * (the padding row) for an index outside it and count the event in a device word.  okge_id_errors copies the count to
+ * the host (a synchronising copy: call it where the reference would have raised -- end of an epoch, before a
+ * checkpoint, in tests) and clears it.  The reference fails inside torch.nn.Embedding instead (model.py:457-460). */
+int okge_id_errors(int64_t *n_out);
+
+/* ---- gradient clipping ----------------------------------------------------------------------------------
+ * torch.nn.utils.clip_grad_norm_(parameters, max_norm) over the two dense gradient tensors, as Trainer.compute_one_batch
+ * applies it before optimizer.step() when args["grad_clip"] > 0 (trainer.py:236-240): both are scaled in place by
+ * min(1, max_norm / (||g||_2 + 1e-6)); the norm (fp32 like torch's, stored as a double) goes to norm_out_dev if given.
+ * workspace: 8448 bytes. */
+int okge_clip_grad_norm(float *g0, int64_t n0, float *g1, int64_t n1, float max_norm, double *norm_out_dev, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* out[b] = log sum_r exp(parts[r][b]): the global log_softmax denominator of the sharded KL loss from the all-gathered
+ * per-shard row log-sum-exps of okge_row_logsumexp (trainer.py:99-101). */
+int okge_merge_logsumexp(const float *parts, int32_t world, int32_t B, float *out, void *stream);
+
 /* ---- measurement ------------------------------------------------------------------------------------
  * When enabled, every kernel launch of the calls above is bracketed by HIP events on its stream.
  * okge_timing_collect synchronises the events and returns per-kernel totals since the last reset:

@@ -8,5 +8,6 @@ from . import _native  # noqa: F401
 from ._native import OkgeError, build_native  # noqa: F401
 
 from . import model, token_pooled  # noqa: F401,E402  (token_pooled registers its classes in model.Models)
+from . import optim  # noqa: F401,E402  (registers OkgeAdagrad in torch.optim for the reference's OptimRegime)
 
 __all__ = ["OkgeError", "build_native"]

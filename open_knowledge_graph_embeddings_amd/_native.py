@@ -31,7 +31,7 @@ EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_t
            "okge_prefix_backward", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
            "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_phase", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
            "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
-           "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -237,6 +237,12 @@ def lib():
     L.okge_adagrad_step2.restype = c_int32
     L.okge_adagrad_step2.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_float, c_float, c_float, c_int32, c_void_p]
+    L.okge_id_errors.restype = c_int32
+    L.okge_id_errors.argtypes = [POINTER(c_int64)]
+    L.okge_clip_grad_norm.restype = c_int32
+    L.okge_clip_grad_norm.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_size_t, c_void_p]
+    L.okge_merge_logsumexp.restype = c_int32
+    L.okge_merge_logsumexp.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_void_p]
     L.okge_filtered_ranks.restype = c_int32
     L.okge_filtered_ranks.argtypes = [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p]
@@ -249,6 +255,21 @@ def lib():
         raise OkgeError("libokge_hip.so ABI version mismatch")
     _LIB = L
     return L
+
+
+def id_errors():
+    """number of out-of-range ids the kernels met since the last call (they substituted row 0); synchronises"""
+    n = c_int64(0)
+    check(lib().okge_id_errors(ctypes.byref(n)), "okge_id_errors")
+    return int(n.value)
+
+
+def check_ids():
+    """raise if a kernel met an out-of-range id (the reference raises inside torch.nn.Embedding, model.py:457-460)"""
+    n = id_errors()
+    if n:
+        raise OkgeError(f"{n} out-of-range id(s) reached the kernels (row 0 was used instead): entity / relation / candidate "
+                        f"ids must lie inside their tables")
 
 
 def check(rc, what):

@@ -77,6 +77,18 @@ struct ScopedTimer {
     }
 };
 
+// ---- device word counting out-of-range ids (checked_row in the kernels); read and cleared by okge_id_errors ------------
+int *g_id_err = nullptr;
+int *id_err_ptr()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (hipMalloc(reinterpret_cast<void **>(&g_id_err), sizeof(int)) != hipSuccess) { g_id_err = nullptr; return; }
+        (void)hipMemset(g_id_err, 0, sizeof(int));
+    });
+    return g_id_err;
+}
+
 // ---- helpers ---------------------------------------------------------------------------------------------
 DropDev to_dev(const okge_dropout &d)
 {
@@ -98,13 +110,16 @@ DropDev to_dev(const okge_dropout &d)
     return r;
 }
 
-PrefixDev to_dev(const okge_prefix_batch &b, const okge_shard *sh = nullptr)
+PrefixDev to_dev(const okge_prefix_batch &b, const okge_tables *t, const okge_shard *sh = nullptr)
 {
     PrefixDev p;
     p.po_rel = b.po_rel; p.po_obj = b.po_obj; p.sp_subj = b.sp_subj; p.sp_rel = b.sp_rel;
     p.n_po = b.n_po; p.n_sp = b.n_sp;
     p.ent_lo = sh ? sh->ent_lo : 0;
-    p.ent_hi = sh ? sh->ent_hi : 0x7fffffff;
+    p.ent_hi = sh ? sh->ent_hi : t->n_ent;          // unsharded: the range IS the table, an id outside it is an error
+    p.whole_table = sh ? 0 : 1;
+    p.n_rel = t->n_rel;
+    p.id_err = id_err_ptr();
     p.drop_po_ent = to_dev(b.drop_po_ent); p.drop_po_rel = to_dev(b.drop_po_rel);
     p.drop_sp_ent = to_dev(b.drop_sp_ent); p.drop_sp_rel = to_dev(b.drop_sp_rel);
     return p;
@@ -219,6 +234,8 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
 {
     std::memset(&a, 0, sizeof(a));
     a.E = c->table ? c->table : t->E;       // table the candidate rows are gathered from
+    a.n_table_rows = c->table ? c->table_rows : t->n_ent;
+    a.id_err = id_err_ptr();
     a.cand_ids = c->ids;
     a.cand_first = c->first_id;
     a.Q = ws ? reinterpret_cast<const float *>(ws + g.off_Q) : nullptr;
@@ -313,7 +330,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     if (!workspace || workspace_bytes < need) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
-    const PrefixDev p = to_dev(*batch);
+    const PrefixDev p = to_dev(*batch, t);
     {
         ScopedTimer tm("encode_queries", st);
         hipError_t e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q),
@@ -365,7 +382,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         ScopedTimer tm("encode_queries", st);
         PrefixDev p;
         std::memset(&p, 0, sizeof(p));
-        if (!q_ext) p = to_dev(*batch, sh);
+        if (!q_ext) p = to_dev(*batch, t, sh);
         e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
                                   q_ext ? 0 : g.Bpad, nullptr, pos->col, pos->nnz,
                                   reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles, g.tile_w, cand_col0, st);
@@ -438,7 +455,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         if (g.b_split > 1) {                        // (few candidate tiles: always a single range)
             ScopedTimer tm("dc_reduce", st);
             e = launch_dc_reduce(a.dC_slab, g.b_split, g.tiles * NT, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
-                                 a.grads_zero, dE, st);
+                                 a.grads_zero, dE, a.n_table_rows, a.id_err, st);
             if (e != hipSuccess) return fail_hip(e, "dc_reduce");
         }
         ScopedTimer tm("dq", st);
@@ -462,7 +479,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     }
     {
         ScopedTimer tm("prefix_backward", st);      // + the deterministic loss reduction (one extra workgroup)
-        const PrefixDev p = to_dev(*batch, sh);
+        const PrefixDev p = to_dev(*batch, t, sh);
         e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, nullptr, dE, dR,
                                    a.loss_partial, g.ktiles * g.b_split, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
@@ -510,7 +527,7 @@ int okge_encode_queries(const okge_tables *t, const okge_shard *sh, const okge_p
     if (int rc = check_shard(t, sh)) return rc;
     if ((!Q && !ent_rows) || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad query block");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const PrefixDev p = to_dev(*batch, sh);
+    const PrefixDev p = to_dev(*batch, t, sh);
     ScopedTimer tm("encode_queries", st);
     hipError_t e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, Q, (int)ldq,
                                          okge_query_rows(batch->n_po + batch->n_sp), ent_rows, nullptr, 0, nullptr, 0,
@@ -528,7 +545,8 @@ int okge_fold_queries(const okge_tables *t, const okge_prefix_batch *batch, cons
     if (int rc = check_common(t, batch, &none)) return rc;
     if (!ent_rows || !Q || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad query block");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const PrefixDev p = to_dev(*batch);
+    PrefixDev p = to_dev(*batch, t);
+    p.ent_lo = 0; p.ent_hi = 0x7fffffff; p.whole_table = 0;     // entity ids are global here and not dereferenced: only relations are
     ScopedTimer tm("fold_queries", st);
     hipError_t e = launch_fold_queries(t->R, t->d, t->scorer, p, ent_rows, Q, (int)ldq,
                                        okge_query_rows(batch->n_po + batch->n_sp), st);
@@ -615,7 +633,7 @@ int okge_prefix_backward(const okge_tables *t, const okge_shard *sh, const okge_
     if (int rc = check_shard(t, sh)) return rc;
     if (!dQ || !dE || !dR || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad prefix_backward arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const PrefixDev p = to_dev(*batch, sh);
+    const PrefixDev p = to_dev(*batch, t, sh);
     const int B = batch->n_po + batch->n_sp;
     ScopedTimer tm("prefix_backward", st);
     hipError_t e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, dQ, 1, okge_query_rows(B), (int)ldq, ent_rows,
@@ -635,7 +653,7 @@ int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const in
     std::memset(&none, 0, sizeof(none));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ScopedTimer tm("encode_rows", st);
-    hipError_t e = launch_encode_rows(table, d, ids, first_id, n, to_dev(drop ? *drop : none), out, ld_out, st);
+    hipError_t e = launch_encode_rows(table, table_rows, d, ids, first_id, n, to_dev(drop ? *drop : none), out, ld_out, id_err_ptr(), st);
     if (e != hipSuccess) return fail_hip(e, "encode_rows");
     return OKGE_OK;
 }
@@ -681,7 +699,7 @@ int okge_pool_encode(const okge_token_embedder *e, const int32_t *ids, int32_t f
     hipError_t err;
     {
         ScopedTimer tm("pool_rows", st);
-        err = launch_pool_rows(e->W, e->d, e->token_ids, e->max_len, ids, first_id, n, e->pool, raw, ld, st);
+        err = launch_pool_rows(e->W, e->d, e->token_ids, e->max_len, ids, first_id, n, e->pool, raw, ld, e->n_ids, id_err_ptr(), st);
         if (err != hipSuccess) return fail_hip(err, "pool_rows");
     }
     if (!e->bn_weight) {
@@ -723,7 +741,7 @@ int okge_pool_backward(const okge_token_embedder *e, const int32_t *ids, int32_t
     ScopedTimer tm("pool_backward", st);
     hipError_t err = launch_pool_backward(e->W, e->d, e->token_ids, e->max_len, ids, first_id, n, e->pool, raw, ld, d_out, ld,
                                           bn ? saved : nullptr, e->bn_weight, d_bn_weight, d_bn_bias, dW,
-                                          static_cast<float *>(workspace), st);
+                                          static_cast<float *>(workspace), e->n_ids, st);
     if (err != hipSuccess) return fail_hip(err, "pool_backward");
     return OKGE_OK;
 }
@@ -911,10 +929,10 @@ static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_pref
             e = hipMemsetAsync(counts, 0, (size_t)n_groups * 2 * sizeof(int32_t), st);
             if (e != hipSuccess) return fail_hip(e, "clear rank counters");
         }
-        const PrefixDev p = to_dev(*batch);
+        const PrefixDev p = to_dev(*batch, t);
         ScopedTimer tm("eval_points", st);
-        e = launch_eval_points(t->E, t->R, t->d, t->scorer, p, Q, g.ldq, g.Bpad, g.KB, cand->ids, cand->first_id, row_ptr, grp_ptr,
-                               ids, filt_ptr, filt_col, tru, fx, st);
+        e = launch_eval_points(t->E, t->R, t->d, t->scorer, p, Q, g.ldq, g.Bpad, g.KB, cand->ids, cand->first_id, cand->n, t->n_ent, row_ptr,
+                               grp_ptr, ids, filt_ptr, filt_col, tru, fx, st);
         if (e != hipSuccess) return fail_hip(e, "eval_points");
     }
     FusedArgs a;
@@ -982,6 +1000,52 @@ int okge_rank_counts(const float *scores, int64_t ld_scores, int32_t B, int32_t 
     hipError_t e = launch_ranks(scores, ld_scores, B, n_local, filt_ptr, filt_col, row_ptr, nullptr, nullptr, nullptr, col0,
                                 true_scores, nullptr, counts, st);
     if (e != hipSuccess) return fail_hip(e, "ranks<counts>");
+    return OKGE_OK;
+}
+
+int okge_id_errors(int64_t *n_out)
+{
+    int *p = id_err_ptr();
+    if (!p || !n_out) return fail(OKGE_ERR_INVALID, "no id error word");
+    int v = 0;
+    hipError_t e = hipMemcpy(&v, p, sizeof(int), hipMemcpyDeviceToHost);       // synchronises: call it when you would sync anyway
+    if (e != hipSuccess) return fail_hip(e, "read id error word");
+    if (v) {
+        e = hipMemset(p, 0, sizeof(int));
+        if (e != hipSuccess) return fail_hip(e, "clear id error word");
+    }
+    *n_out = v;
+    return OKGE_OK;
+}
+
+int okge_clip_grad_norm(float *g0, int64_t n0, float *g1, int64_t n1, float max_norm, double *norm_out_dev, void *workspace,
+                        size_t workspace_bytes, void *stream)
+{
+    if (!g0 || n0 < 0 || n1 < 0 || (n1 > 0 && !g1) || !(max_norm > 0.f)) return fail(OKGE_ERR_INVALID, "bad clip_grad_norm arguments");
+    constexpr int NP = 1024;
+    if (!workspace || workspace_bytes < NP * sizeof(double) + 256) return fail(OKGE_ERR_WORKSPACE, "workspace too small (8448 bytes)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    double *partial = static_cast<double *>(workspace);
+    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + NP * sizeof(double));
+    hipError_t e;
+    {
+        ScopedTimer tm("clip_grad_norm", st);
+        e = launch_clip_coef(g0, n0, g1 ? g1 : g0, g1 ? n1 : 0, max_norm, partial, NP, coef, norm_out_dev, st);
+        if (e != hipSuccess) return fail_hip(e, "clip_coef");
+        e = launch_scale(g0, n0, coef, st);
+        if (e == hipSuccess && g1 && n1 > 0) e = launch_scale(g1, n1, coef, st);
+    }
+    if (e != hipSuccess) return fail_hip(e, "scale gradients");
+    return OKGE_OK;
+}
+
+int okge_merge_logsumexp(const float *parts, int32_t world, int32_t B, float *out, void *stream)
+{
+    if (!parts || !out || world <= 0 || B <= 0) return fail(OKGE_ERR_INVALID, "bad merge_logsumexp arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("merge_lse", st);
+    hipError_t e = launch_merge_lse(parts, world, B, out, st);
+    if (e != hipSuccess) return fail_hip(e, "merge_lse");
     return OKGE_OK;
 }
 

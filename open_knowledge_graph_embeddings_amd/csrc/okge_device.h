@@ -88,6 +88,17 @@ __device__ __forceinline__ v4f mfma16(float a, float b, v4f c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Ids live in device memory and are trusted for speed, but never for safety: a row index outside its table is replaced
+// by row 0 (the padding row every table has) and counted in a device word the host reads lazily (okge_id_errors).
+__device__ __forceinline__ int64_t checked_row(int64_t id, int64_t n_rows, int *err)
+{
+    if ((uint64_t)id >= (uint64_t)n_rows) {
+        if (err) atomicAdd(err, 1);
+        return 0;
+    }
+    return id;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

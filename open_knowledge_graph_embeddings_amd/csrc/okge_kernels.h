@@ -44,6 +44,8 @@ struct FusedArgs {
     int32_t        d, KB, LDK, cand_first, N, B, Bpad, ldq, ldg, nnz, b_per_block, loss_kind, x_vec_ok, grads_zero, cand_exclusive;
     float          y_pos, y_neg, inv_norm;
     int32_t        cand_col0;  // global column (candidate position) of local candidate 0: positives, dropout keys
+    int64_t        n_table_rows;   // rows of the table `E` points to: candidate ids are checked against it (checked_row)
+    int           *id_err;         // device word counting out-of-range ids
     int32_t        loss_only;  // forward + loss only: no G store, no dC product, no write-back
 };
 
@@ -59,6 +61,9 @@ struct PrefixDev {
     const int32_t *po_rel, *po_obj, *sp_subj, *sp_rel;
     int32_t        n_po, n_sp;
     int32_t        ent_lo, ent_hi;   // global entity ids [ent_lo, ent_hi) live in the local table (row = id - ent_lo)
+    int32_t        n_rel;            // rows of the relation table; whole_table: ent range IS the table (an id outside is an error,
+    int32_t        whole_table;      // not another rank's row)
+    int           *id_err;           // device word counting out-of-range ids
     DropDev        drop_po_ent, drop_po_rel, drop_sp_ent, drop_sp_rel;
 };
 
@@ -84,36 +89,44 @@ hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, h
 hipError_t launch_kl_count_pos(const int32_t *pos_row, int nnz, int Bpad, float *row_ysum, hipStream_t st);
 hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, float *run, int first, int last, float *row_lse,
                              hipStream_t st);
-hipError_t launch_encode_rows(const float *table, int d, const int32_t *ids, int first_id, int n, const DropDev &drop,
-                              float *out, int64_t ld_out, hipStream_t st);
+hipError_t launch_encode_rows(const float *table, int64_t table_rows, int d, const int32_t *ids, int first_id, int n,
+                              const DropDev &drop, float *out, int64_t ld_out, int *id_err, hipStream_t st);
 hipError_t launch_scale(float *x, int64_t n, const float *alpha_dev, hipStream_t st);
 hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, float wd, float eps, int zero_grad,
                           hipStream_t st);
 hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p1, float *g1, float *s1, int64_t n1,
                            float lr, float wd, float eps, int zero_grad, hipStream_t st);
+// torch.nn.utils.clip_grad_norm_ over two gradient tensors: coef = min(1, max_norm / (||g|| + 1e-6)) -> coef_dev (fp32),
+// ||g|| -> norm_dev (double); the caller scales with launch_scale (trainer.py:236-240)
+hipError_t launch_clip_coef(const float *g0, int64_t n0, const float *g1, int64_t n1, float max_norm, double *partial,
+                            int n_partial, float *coef_dev, double *norm_dev, hipStream_t st);
+// log-sum-exp over `world` per-shard row log-sum-exps: out[b] = log sum_r exp(parts[r][b])  (sharded KL loss)
+hipError_t launch_merge_lse(const float *parts, int world, int B, float *out, hipStream_t st);
 // error text for okge_last_error(), shared by the translation units of the C ABI (defined in okge_api.hip)
 int report_error(int code, const std::string &msg);
 
 size_t pool_workspace_bytes(int n, int d);
 hipError_t launch_pool_rows(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
-                            int pool, float *out, int64_t ld, hipStream_t st);
+                            int pool, float *out, int64_t ld, int n_ids, int *id_err, hipStream_t st);
 hipError_t launch_bn_stats(const float *X, int64_t ldx, int n, int d, float eps, float momentum, float *saved,
                            float *run_mean, float *run_var, float *partial, hipStream_t st);
 hipError_t launch_bn_apply(const float *X, int64_t ldx, int n, int d, const float *mean, const float *rstd_or_var, int is_var,
                            float eps, const float *weight, const float *bias, float *Y, int64_t ldy, hipStream_t st);
 hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
                                 int pool, const float *X, int64_t ldx, const float *DY, int64_t lddy, float *saved,
-                                const float *weight, float *d_weight, float *d_bias, float *dW, float *partial, hipStream_t st);
+                                const float *weight, float *d_weight, float *d_bias, float *dW, float *partial, int n_ids,
+                                hipStream_t st);
 hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
-                            int cand_first, int exclusive, int grads_zero, float *dE, hipStream_t st);
+                            int cand_first, int exclusive, int grads_zero, float *dE, int64_t table_rows, int *id_err,
+                            hipStream_t st);
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_rank_metrics(const int64_t *ranks, int64_t n, double *acc, hipStream_t st);
 // fused evaluation (okge_evaluate_fused): point scores in the tile kernel's summation order, then ranks from the counts
 hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
-                              int KB, const int32_t *cand_ids, int cand_first, const int64_t *row_ptr, const int64_t *grp_ptr,
-                              const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col, float *true_out,
-                              float *filt_x, hipStream_t st);
+                              int KB, const int32_t *cand_ids, int cand_first, int n_cand, int64_t table_rows, const int64_t *row_ptr,
+                              const int64_t *grp_ptr, const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col,
+                              float *true_out, float *filt_x, hipStream_t st);
 hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int tiles, const float *true_scores, const float *filt_x, const int64_t *filt_ptr,
                              const int64_t *row_ptr, int B, int64_t n_groups, int64_t *ranks, double *acc, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,

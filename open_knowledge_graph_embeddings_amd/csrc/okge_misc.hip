@@ -31,6 +31,9 @@ __device__ __forceinline__ RowSrc row_source(const PrefixDev &p, int b)
     }
     r.owned = gid >= p.ent_lo && gid < p.ent_hi;
     r.ent = gid - p.ent_lo;
+    int *err = threadIdx.x == 0 ? p.id_err : nullptr;
+    if (!r.owned && (p.whole_table || gid < 0) && err) atomicAdd(err, 1);   // not "another rank's row": a bad id
+    r.rel = checked_row(r.rel, p.n_rel, err);
     return r;
 }
 
@@ -169,7 +172,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 // (one thread per 4 columns; rows of repeated candidate ids accumulate with atomics)
 __global__ __launch_bounds__(256) void dc_reduce_kernel(const float *__restrict__ slab, int nsplit, int rows_pad, int D16,
                                                         int N, int d, const int32_t *__restrict__ cand_ids, int cand_first,
-                                                        int exclusive, int grads_zero, float *__restrict__ dE)
+                                                        int exclusive, int grads_zero, float *__restrict__ dE,
+                                                        int64_t table_rows, int *__restrict__ id_err)
 {
     const int q4 = D16 >> 2;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void dc_reduce_kernel(const float *__restrict_
         const float4 v = *reinterpret_cast<const float4 *>(slab + ((size_t)sidx * rows_pad + n) * D16 + k);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    const int64_t cid = cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n;
+    const int64_t cid = checked_row(cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n, table_rows, id_err);
     float *dst = dE + cid * d + k;
     const float v[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
@@ -437,12 +441,12 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, flo
     }
 }
 
-__global__ __launch_bounds__(128) void encode_rows_kernel(const float *__restrict__ table, int d,
+__global__ __launch_bounds__(128) void encode_rows_kernel(const float *__restrict__ table, int64_t table_rows, int d,
                                                           const int32_t *__restrict__ ids, int first_id, const DropDev drop,
-                                                          float *__restrict__ out, int64_t ld_out)
+                                                          float *__restrict__ out, int64_t ld_out, int *__restrict__ id_err)
 {
     const int i = blockIdx.x;
-    const int64_t row = ids ? (int64_t)ids[i] : (int64_t)first_id + i;
+    const int64_t row = checked_row(ids ? (int64_t)ids[i] : (int64_t)first_id + i, table_rows, threadIdx.x == 0 ? id_err : nullptr);
     const float *src = table + row * d;
     float *dst = out + (size_t)i * ld_out;
     for (int k = threadIdx.x; k < d; k += blockDim.x) dst[k] = src[k] * drop_mult1(drop, (uint32_t)i, k, d);
@@ -739,6 +743,49 @@ __global__ __launch_bounds__(256) void score_triples_kernel(const float *__restr
     if (lane == 0) out[i] = acc;
 }
 
+// ---- gradient clipping (trainer.py:236-240: torch.nn.utils.clip_grad_norm_) and the sharded KL loss' row log-sum-exp --
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float *__restrict__ g0, int64_t n0, const float *__restrict__ g1,
+                                                             int64_t n1, double *__restrict__ partial)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = first; i < n0; i += stride) acc += (double)g0[i] * (double)g0[i];
+    for (int64_t i = first; i < n1; i += stride) acc += (double)g1[i] * (double)g1[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double *__restrict__ partial, int n, float max_norm,
+                                                        float *__restrict__ coef, double *__restrict__ norm_out)
+{
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(red[0] + red[1] + red[2] + red[3]);        // torch keeps the norm in fp32
+        const float c = max_norm / (total + 1e-6f);
+        coef[0] = c < 1.f ? c : 1.f;
+        if (norm_out) norm_out[0] = (double)total;
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_lse_kernel(const float *__restrict__ parts, int world, int B, float *__restrict__ out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float m = -INFINITY;
+    for (int r = 0; r < world; ++r) m = fmaxf(m, parts[(size_t)r * B + b]);
+    float sacc = 0.f;
+    for (int r = 0; r < world; ++r) sacc += expf(parts[(size_t)r * B + b] - m);
+    out[b] = m > -INFINITY ? m + logf(sacc) : -INFINITY;
+}
+
 // ---- fused evaluation (okge_evaluate_fused) ----------------------------------------------------------------------
 // score(b, n) exactly as fused_tile_kernel<KB, MODE_SCORE/MODE_COUNT> computes it: v_mfma_f32_16x16x4_f32 is a
 // k-ordered fp32 fma chain (MI355X guide), and the tile kernel feeds it k = 16r + 4s + j in the order r, j, s -- so a
@@ -773,6 +820,7 @@ __device__ __forceinline__ float point_score(const float *__restrict__ q /* LDS,
 __global__ __launch_bounds__(256) void eval_points_kernel(const float *__restrict__ E, const float *__restrict__ R, int d,
                                                           int scorer, const PrefixDev p, float *__restrict__ Q, int ldq,
                                                           int KB, const int32_t *__restrict__ cand_ids, int cand_first,
+                                                          int n_cand, int64_t table_rows,
                                                           const int64_t *__restrict__ row_ptr,
                                                           const int64_t *__restrict__ grp_ptr,
                                                           const int32_t *__restrict__ ids,
@@ -787,8 +835,9 @@ __global__ __launch_bounds__(256) void eval_points_kernel(const float *__restric
     for (int k = threadIdx.x; k < ldq; k += blockDim.x) Q[(size_t)b * ldq + k] = k < 16 * KB ? qs[k] : 0.f;
     if (b >= B) return;
     const bool vec_ok = (d & 3) == 0;
-    auto cand_row = [&](int col) {
-        const int64_t cid = cand_ids ? (int64_t)cand_ids[col] : (int64_t)cand_first + col;
+    auto cand_row = [&](int col) {            // col: a position in the candidate list (checked), then an entity row (checked)
+        col = (int)checked_row(col, n_cand, p.id_err);
+        const int64_t cid = checked_row(cand_ids ? (int64_t)cand_ids[col] : (int64_t)cand_first + col, table_rows, p.id_err);
         return E + cid * d;
     };
     const int64_t g_lo = row_ptr[b], g_hi = row_ptr[b + 1];
@@ -893,12 +942,13 @@ hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *o
 }
 
 hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
-                            int cand_first, int exclusive, int grads_zero, float *dE, hipStream_t st)
+                            int cand_first, int exclusive, int grads_zero, float *dE, int64_t table_rows, int *id_err,
+                            hipStream_t st)
 {
     const int64_t total = (int64_t)N * (D16 / 4);
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(dc_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, nsplit, rows_pad, D16, N,
-                       d, cand_ids, cand_first, exclusive, grads_zero, dE);
+                       d, cand_ids, cand_first, exclusive, grads_zero, dE, table_rows, id_err);
     return hipGetLastError();
 }
 
@@ -955,11 +1005,11 @@ hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, f
     return hipGetLastError();
 }
 
-hipError_t launch_encode_rows(const float *table, int d, const int32_t *ids, int first_id, int n, const DropDev &drop,
-                              float *out, int64_t ld_out, hipStream_t st)
+hipError_t launch_encode_rows(const float *table, int64_t table_rows, int d, const int32_t *ids, int first_id, int n,
+                              const DropDev &drop, float *out, int64_t ld_out, int *id_err, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encode_rows_kernel, dim3(n), dim3(128), 0, st, table, d, ids, first_id, drop, out, ld_out);
+    hipLaunchKernelGGL(encode_rows_kernel, dim3(n), dim3(128), 0, st, table, table_rows, d, ids, first_id, drop, out, ld_out, id_err);
     return hipGetLastError();
 }
 
@@ -1005,13 +1055,13 @@ hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int
 namespace okge {
 
 hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
-                              int KB, const int32_t *cand_ids, int cand_first, const int64_t *row_ptr, const int64_t *grp_ptr,
-                              const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col, float *true_out,
-                              float *filt_x, hipStream_t st)
+                              int KB, const int32_t *cand_ids, int cand_first, int n_cand, int64_t table_rows, const int64_t *row_ptr,
+                              const int64_t *grp_ptr, const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col,
+                              float *true_out, float *filt_x, hipStream_t st)
 {
     if (Bpad <= 0) return hipSuccess;
     hipLaunchKernelGGL(eval_points_kernel, dim3(Bpad), dim3(256), 0, st, E, R, d, scorer, p, Q, ldq, KB, cand_ids, cand_first,
-                       row_ptr, grp_ptr, ids, filt_ptr, filt_col, true_out, filt_x);
+                       n_cand, table_rows, row_ptr, grp_ptr, ids, filt_ptr, filt_col, true_out, filt_x);
     return hipGetLastError();
 }
 
@@ -1022,6 +1072,25 @@ hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int ti
     if (n_groups <= 0) return hipSuccess;
     hipLaunchKernelGGL(eval_ranks_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, st, counts, slab, tiles, true_scores, filt_x,
                        filt_ptr, row_ptr, B, n_groups, ranks, acc);
+    return hipGetLastError();
+}
+
+}  // namespace okge
+
+namespace okge {
+
+hipError_t launch_clip_coef(const float *g0, int64_t n0, const float *g1, int64_t n1, float max_norm, double *partial,
+                            int n_partial, float *coef_dev, double *norm_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(n_partial), dim3(256), 0, st, g0, n0, g1, n1, partial);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, partial, n_partial, max_norm, coef_dev, norm_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_lse(const float *parts, int world, int B, float *out, hipStream_t st)
+{
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(merge_lse_kernel, dim3((B + 255) / 256), dim3(256), 0, st, parts, world, B, out);
     return hipGetLastError();
 }
 

@@ -19,16 +19,19 @@ namespace {
 constexpr int POOL_SUM = 0, POOL_MEAN = 1, POOL_MAX = 2;
 constexpr int STAT_ROWS = 32;          // rows per partial-sum workgroup
 
-__device__ __forceinline__ int row_id(const int32_t *ids, int first_id, int i) { return ids ? ids[i] : first_id + i; }
+__device__ __forceinline__ int row_id(const int32_t *ids, int first_id, int i, int n_ids, int *id_err)
+{
+    return (int)checked_row(ids ? ids[i] : first_id + i, n_ids, id_err);      // row of the token-id table
+}
 
 // out[i][k] = pool_t W[tok(i,t)][k].  Padded positions (token 0) take part: the table's row 0 is an ordinary row
 // whose gradient is suppressed (padding_idx), not a zero row (model.py:660-661 re-initialises the whole weight).
 __global__ __launch_bounds__(128) void pool_rows_kernel(const float *__restrict__ W, int d, const int32_t *__restrict__ tokens,
                                                         int L, const int32_t *__restrict__ ids, int first_id, int pool,
-                                                        float *__restrict__ out, int64_t ld)
+                                                        float *__restrict__ out, int64_t ld, int n_ids, int *__restrict__ id_err)
 {
     const int i = blockIdx.x;
-    const int32_t *tok = tokens + (size_t)row_id(ids, first_id, i) * L;
+    const int32_t *tok = tokens + (size_t)row_id(ids, first_id, i, n_ids, threadIdx.x ? nullptr : id_err) * L;
     float inv = 1.f;
     if (pool == POOL_MEAN) {
         int len = 0;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void pool_backward_kernel(const float *__restr
                                                             const float *__restrict__ X, int64_t ldx,
                                                             const float *__restrict__ DY, int64_t lddy, int n,
                                                             const float *__restrict__ saved, const float *__restrict__ weight,
-                                                            float *__restrict__ dW)
+                                                            float *__restrict__ dW, int n_ids)
 {
     extern __shared__ float hot[];                      // [HOT_TOKENS][d]
     __shared__ uint32_t hot_seen;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void pool_backward_kernel(const float *__restr
     const int r0 = blockIdx.x * POOL_BWD_ROWS, nr = min(n, r0 + POOL_BWD_ROWS) - r0;
     for (int i = threadIdx.x; i < HOT_TOKENS * d; i += blockDim.x) hot[i] = 0.f;
     for (int i = threadIdx.x; i < nr * L; i += blockDim.x)
-        toks[i / L][i % L] = tokens[(size_t)row_id(ids, first_id, r0 + i / L) * L + i % L];
+        toks[i / L][i % L] = tokens[(size_t)row_id(ids, first_id, r0 + i / L, n_ids, nullptr) * L + i % L];
     if (threadIdx.x == 0) hot_seen = 0;
     __syncthreads();
     if (threadIdx.x < nr) {
@@ -237,10 +240,10 @@ size_t pool_workspace_bytes(int n, int d)
 }
 
 hipError_t launch_pool_rows(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
-                            int pool, float *out, int64_t ld, hipStream_t st)
+                            int pool, float *out, int64_t ld, int n_ids, int *id_err, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pool_rows_kernel, dim3(n), dim3(128), 0, st, W, d, tokens, L, ids, first_id, pool, out, ld);
+    hipLaunchKernelGGL(pool_rows_kernel, dim3(n), dim3(128), 0, st, W, d, tokens, L, ids, first_id, pool, out, ld, n_ids, id_err);
     return hipGetLastError();
 }
 
@@ -267,7 +270,8 @@ hipError_t launch_bn_apply(const float *X, int64_t ldx, int n, int d, const floa
 
 hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
                                 int pool, const float *X, int64_t ldx, const float *DY, int64_t lddy, float *saved,
-                                const float *weight, float *d_weight, float *d_bias, float *dW, float *partial, hipStream_t st)
+                                const float *weight, float *d_weight, float *d_bias, float *dW, float *partial, int n_ids,
+                                hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
     if (saved) {
@@ -278,7 +282,7 @@ hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, in
     }
     hipLaunchKernelGGL(pool_backward_kernel, dim3((n + POOL_BWD_ROWS - 1) / POOL_BWD_ROWS), dim3(256),
                        sizeof(float) * HOT_TOKENS * d, st, W, d, tokens, L, ids, first_id, pool, X, ldx, DY, lddy, n, saved,
-                       weight, dW);
+                       weight, dW, n_ids);
     return hipGetLastError();
 }
 

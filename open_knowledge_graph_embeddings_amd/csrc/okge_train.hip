@@ -38,7 +38,8 @@ namespace okge {
 template <int KB>
 __device__ __forceinline__ void load_cand_tile(float *Cs, uint8_t *keepb, float *Cm, const float *__restrict__ E,
                                                int d, const int32_t *__restrict__ cand_ids, int cand_first, int N,
-                                               int n0, const DropDev &drop, bool vec_ok, int tid, int cand_col0)
+                                               int n0, const DropDev &drop, bool vec_ok, int tid, int cand_col0,
+                                               int64_t table_rows, int *id_err)
 {
     constexpr int LDK = lds_ld(16 * KB), NO = 2 * KB, NOIT = (NO + 7) / 8;
 #pragma unroll
@@ -47,7 +48,7 @@ __device__ __forceinline__ void load_cand_tile(float *Cs, uint8_t *keepb, float 
         const int n = n0 + r;
         const bool valid = n < N;
         int64_t cid = 0;
-        if (valid) cid = cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n;
+        if (valid) cid = checked_row(cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n, table_rows, (tid & 7) ? nullptr : id_err);
         const float *row = E + cid * d;
         float4 v0[NOIT], v1[NOIT];
 #pragma unroll
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
     };
     fetch_chunk(b_begin);
     load_cand_tile<KB>(Cs, nullptr, nullptr, a.E, d, a.cand_ids, a.cand_first, a.N, n0, a.drop_c, vec_ok, tid,
-                       a.cand_col0);
+                       a.cand_col0, a.n_table_rows, a.id_err);
 
     // MODE_COUNT: the group range of the lane's row is loaded ONE CHUNK AHEAD and the row's first RK_PRE true scores before
     // the score product, so that the counting loop does not wait on dependent global loads (one workgroup of four

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(Tile32Cfg<KB>::THREADS, Tile32Cfg<KB>::WAVES_PER_SI
         const int n = n0 + r8;
         const bool valid = n < a.N;
         int64_t cid = 0;
-        if (valid) cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
+        if (valid) cid = checked_row(a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n, a.n_table_rows, q8 ? nullptr : a.id_err);
         const float *row = a.E + cid * d;
         float *cm = (TRAIN && blockIdx.y == 0 && !a.loss_only) ? a.Cm + (size_t)n * (16 * KB) : nullptr;
         v4f v0[NOIT], v1[NOIT];
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(Tile32Cfg<KB>::THREADS, Tile32Cfg<KB>::WAVES_PER_SI
         }
         const int n = n0 + r8;
         if (!a.loss_only && n < a.N) {
-            const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
+            const int64_t cid = checked_row(a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n, a.n_table_rows, nullptr);
             float *drow = a.dE + cid * d;
             const bool exclusive = gridDim.y == 1 && a.cand_exclusive;    // one workgroup per entity row: plain stores
             // batch split over blockIdx.y: every workgroup stores ITS partial rows into a slab (plain 16-byte stores);

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
         const int n = n0 + r8;
         const bool valid = n < a.N;
         int64_t cid = 0;
-        if (valid) cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
+        if (valid) cid = checked_row(a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n, a.n_table_rows, q8 ? nullptr : a.id_err);
         const float *row = a.E + cid * d;
         v4f v0[NOIT], v1[NOIT];
 #pragma unroll
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
     TL_STAMP_AT(44);       // loss partial out
     const int n = n0 + r8;
     if (!a.loss_only && n < a.N) {
-        const int64_t cid = a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n;
+        const int64_t cid = checked_row(a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n, a.n_table_rows, nullptr);
         float *drow = a.dE + cid * d;
         const bool exclusive = gridDim.y == 1 && a.cand_exclusive;    // one workgroup per entity row: plain stores
         // batch split over blockIdx.y: every workgroup stores ITS partial rows into a slab (plain 16-byte stores);

@@ -400,6 +400,22 @@ class HotPath:
                                             g1.data_ptr(), s1.data_ptr(), p1.numel(), float(lr), float(weight_decay),
                                             float(eps), int(zero_grad), self._stream()), "okge_adagrad_step2")
 
+    def clip_grad_norm_(self, g0, g1, max_norm, norm_out=None):
+        """torch.nn.utils.clip_grad_norm_ over two dense gradient tensors, in place (trainer.py:236-240)"""
+        if getattr(self, "_clip_ws", None) is None:
+            self._clip_ws = torch.empty(8448, dtype=torch.uint8, device=self.device)
+        N.check(self.lib.okge_clip_grad_norm(g0.data_ptr(), g0.numel(), _ptr(g1), 0 if g1 is None else g1.numel(), float(max_norm),
+                                             _ptr(norm_out), self._clip_ws.data_ptr(), self._clip_ws.numel(), self._stream()),
+                "okge_clip_grad_norm")
+
+    def merge_logsumexp(self, parts, out=None):
+        """parts (world, B) fp32 per-shard row log-sum-exps -> (B,) log-sum-exp over the shards"""
+        world, B = parts.shape
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=self.device)
+        N.check(self.lib.okge_merge_logsumexp(parts.data_ptr(), world, B, out.data_ptr(), self._stream()), "okge_merge_logsumexp")
+        return out
+
     def filtered_ranks(self, scores, filt_ptr, filt_col, row_ptr, grp_ptr, ids):
         """int64 ranks per answer group; all index arrays on the device (int64 ptr arrays, int32 ids)."""
         n_groups = int(grp_ptr.numel()) - 1

@@ -94,7 +94,7 @@ class ShardedTrainStep:
             lse = eng.row_logsumexp(self.E, self.R, self.scorer, qe[0], batch.B, local, self.shard)
             every = torch.empty(self.world * batch.B, dtype=lse.dtype, device=lse.device)
             dist.all_gather_into_tensor(every, lse, group=self.group)
-            row_lse = torch.logsumexp(every.view(self.world, batch.B), dim=0).contiguous()
+            row_lse = eng.merge_logsumexp(every.view(self.world, batch.B))
         eng.train_tiles(self.E, self.R, self.scorer, qe[0], local, self.shard, self.dE, dq, self.n_cand_global,
                         loss=self.loss, label_smoothing=self.label_smoothing,
                         normalizer=float(batch.B) * float(self.n_cand_global), loss_out=self.loss_out, grads_zero=True,

@@ -239,7 +239,8 @@ class TokenPooledTrainStep:
 # ------------------------------------------------------------------------------------------------------------------
 class UnigramPoolingRelationEmbedder(RelationEmbedder):
     """openkge/model.py:561-796.  Implemented: pool sum|mean|max, normalize None|'batchnorm', dropout; not implemented
-    (raise): normalize='norm', activation, project_relation, sparse gradients."""
+    (raise): normalize='norm', activation, project_relation, sparse gradients.  Training: TokenPooledTrainStep (fused, own
+    Adagrad) or trainer.AddLossModule (autograd bridge: any torch optimizer over the module's parameters)."""
 
     def __init__(self, entity_slot_size, relation_slot_size, train_data, pool='sum', normalize=None, dropout=0.0,
                  entity_dropout=None, relation_dropout=None, sparse=False, init_std=0.01, activation=None,
@@ -357,6 +358,68 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
         if batch.sp_subj is not None:
             return self._score(self.encode_subj(batch.sp_subj), self.encode_rel(batch.sp_rel), many, prefix=True, sp=True, po=False)
         return self._score(many, self.encode_rel(batch.po_rel), self.encode_obj(batch.po_obj), prefix=True, sp=False, po=True)
+
+    # -- AddLossModule / autograd bridge (the reference Trainer's path: trainer.py:142, 206-234) ---------------------
+    def _module_slots(self):
+        slots = []
+        for emb, tok, bn in ((self.entity_embedding, self.entity_token_ids, self.entity_batchnorm),
+                             (self.relation_embedding, self.relation_token_ids, self.relation_batchnorm)):
+            s = TokenSlot(emb.weight.data, tok, self.pool, bn is not None, None if bn is None else bn.weight.data,
+                          None if bn is None else bn.bias.data)
+            if bn is not None:
+                s.running_mean, s.running_var = bn.running_mean, bn.running_var
+            slots.append(s)
+        return slots
+
+    def autograd_step(self, loss, label_smoothing):
+        """the cached TokenPooledTrainStep behind AddLossModule: shares the module's parameters; its optimizer is NOT used
+        (the caller's torch optimizer steps the module parameters)"""
+        st = getattr(self, "_ag_step", None)
+        if st is None or st.loss != loss or st.label_smoothing != label_smoothing or st.entity.W.data_ptr() != self.entity_embedding.weight.data_ptr():
+            e, r = self._module_slots()
+            st = self._ag_step = TokenPooledTrainStep(e, r, self.scorer_name, loss=loss, label_smoothing=label_smoothing,
+                                                      dropout=self.entity_dropout, seed=self.dropout_seed)
+        for sl, bn in ((st.entity, self.entity_batchnorm), (st.relation, self.relation_batchnorm)):
+            sl.dW = torch.zeros_like(sl.W)                        # fresh gradient buffers: the last ones went to autograd
+            if bn is not None:                                     # the module's parameters may have been stepped outside
+                sl.bn[:sl.d].copy_(bn.weight.data)
+                sl.bn[sl.d:].copy_(bn.bias.data)
+                sl.d_bn = torch.zeros_like(sl.d_bn)
+        st.steps = self.dropout_step
+        self.dropout_step += 1
+        return st
+
+    def autograd_params_and_grads(self, st):
+        params, grads = [self.entity_embedding.weight, self.relation_embedding.weight], [st.entity.dW, st.relation.dW]
+        for sl, bn in ((st.entity, self.entity_batchnorm), (st.relation, self.relation_batchnorm)):
+            if bn is not None:
+                params += [bn.weight, bn.bias]
+                grads += [sl.d_bn[:sl.d], sl.d_bn[sl.d:]]
+        return params, grads
+
+    def loss_only(self, batch: H.PrefixBatch, loss, label_smoothing, scores=None):
+        """eval-mode loss (+ scores) of AddLossModule: rows encoded with the running statistics, no dropout"""
+        eng, dev = self.engine(), self.entity_embedding.weight.device
+        n_po, n_sp, n_c = batch.n_po, batch.n_sp, batch.n_candidates
+        if batch.cand_ids is None:
+            cand = self.get_all_obj()[batch.cand_first - self.train_data.min_entities_size:][:n_c] if not self.training else \
+                self._encode(torch.arange(batch.cand_first, batch.cand_first + n_c, dtype=torch.int32, device=dev), False, H.STREAM_CAND).squeeze(1)
+        else:
+            cand = self._encode(batch.cand_ids, False, H.STREAM_CAND).squeeze(1)
+        parts_e, parts_r = [cand], []
+        if n_po:
+            parts_r.append(self.encode_rel(batch.po_rel).squeeze(1))
+            parts_e.append(self.encode_obj(batch.po_obj).squeeze(1))
+        if n_sp:
+            parts_e.append(self.encode_subj(batch.sp_subj).squeeze(1))
+            parts_r.append(self.encode_rel(batch.sp_rel).squeeze(1))
+        EV, RV = torch.cat(parts_e).contiguous(), torch.cat(parts_r).contiguous()
+        ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
+        vb = H.PrefixBatch(po_rel=ar(0, n_po) if n_po else None, po_obj=ar(n_c, n_c + n_po) if n_po else None,
+                           sp_subj=ar(n_c + n_po, n_c + n_po + n_sp) if n_sp else None, sp_rel=ar(n_po, n_po + n_sp) if n_sp else None,
+                           pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=n_c)
+        return eng.forward_backward(EV, RV, self.scorer_name, vb, None, None, loss=loss, label_smoothing=label_smoothing,
+                                    normalizer=1.0, scores=scores, loss_only=True)
 
     def train_step(self, loss="bce", lr=0.1, weight_decay=1e-10, eps=1e-8, label_smoothing=0.0):
         """The training driver for this model: shares the module's parameters (updated in place)."""

@@ -17,7 +17,8 @@ from . import hotpath as H
 class FusedTrainStep:
     def __init__(self, E: torch.Tensor, R: torch.Tensor, scorer: str, loss: str = "bce", lr: float = 0.3,
                  weight_decay: float = 1e-10, eps: float = 1e-8, label_smoothing: float = 0.0,
-                 input_dropout: float = 0.0, relation_input_dropout: float = 0.0, seed: int = 0, engine=None):
+                 input_dropout: float = 0.0, relation_input_dropout: float = 0.0, seed: int = 0, engine=None,
+                 grad_clip: float = 0.0, accumulate: int = 1):
         """Defaults follow config/fb15k237/fb15k237-complex-kge.yaml and the optimizer OptimRegime actually
         builds (utils/optim.py:29,139-160): Adagrad(lr, weight_decay=1e-10, eps=1e-8 leaked from Adam)."""
         self.E, self.R = E, R
@@ -34,6 +35,10 @@ class FusedTrainStep:
         self._grads_zero = True           # fresh buffers; kept true by the zero_grad fused into Adagrad
         self._dE_stale = False            # dE holds last step's values (they get overwritten, not accumulated)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=E.device)
+        # trainer.py:229-244: gradients of `accumulate` consecutive batches are summed before one optimizer step
+        # (batch_size_for_backward = accumulate x batch_size), clipped to `grad_clip` (global 2-norm) if > 0
+        self.grad_clip, self.accumulate = float(grad_clip or 0.0), max(1, int(accumulate))
+        self._accumulated = 0
 
     def state_tensors(self):
         """every tensor a step mutates (GraphedTrainStep snapshots them around its warm-up)"""
@@ -91,11 +96,12 @@ class FusedTrainStep:
             self.dR.data_ptr(), None, 0, ws.data_ptr(), eng._ws_bytes, eng._stream()), "okge_train_forward_backward")
         return self.loss_out
 
-    @staticmethod
-    def _plain(batch: H.PrefixBatch):
-        """int32 contiguous tensors everywhere and no replayed masks: nothing for the generic path to convert"""
+    def _plain(self, batch: H.PrefixBatch):
+        """int32 contiguous tensors ON THE ENGINE'S DEVICE everywhere and no replayed masks: nothing for the generic path
+        to convert (a host tensor's data_ptr handed to a kernel would be a GPU fault)"""
+        dev = self.E.device
         for x in (batch.po_rel, batch.po_obj, batch.sp_subj, batch.sp_rel, batch.pos_row, batch.pos_col, batch.cand_ids):
-            if x is not None and (x.dtype != torch.int32 or not x.is_contiguous() or x.dim() != 1):
+            if x is not None and (x.dtype != torch.int32 or not x.is_contiguous() or x.dim() != 1 or x.device != dev):
                 return False
         return batch.pos_row is not None and batch.cand_table is None
 
@@ -105,7 +111,7 @@ class FusedTrainStep:
             self.dE.zero_()               # a sampled candidate list leaves rows untouched: they must read as zero
             self._dE_stale = False
         self._last_full = self._covers_all_rows(batch)
-        if isinstance(self.engine, H.HotPath) and self._plain(batch) and batch.pos_row.device == self.E.device:
+        if isinstance(self.engine, H.HotPath) and self._plain(batch):
             return self._fast_forward_backward(batch, normalizer)
         self._set_dropout(batch)
         return self.engine.forward_backward(self.E, self.R, self.scorer, batch, self.dE, self.dR, loss=self.loss,
@@ -121,10 +127,17 @@ class FusedTrainStep:
         self._dE_stale = bool(lazy_zero)
 
     def step(self, batch: H.PrefixBatch, normalizer=None):
+        """forward + loss + backward; every `accumulate`-th call also clips (grad_clip > 0) and takes the Adagrad step"""
         self.steps += 1
         loss = self.forward_backward(batch, normalizer)
         self._grads_zero = False
-        self.optimizer_step(lazy_zero=self._last_full)
+        self._accumulated += 1
+        if self._accumulated < self.accumulate:
+            return loss                      # trainer.py:233-234, 246-248: no optimizer step yet, gradients keep adding up
+        self._accumulated = 0
+        if self.grad_clip > 0:
+            self.engine.clip_grad_norm_(self.dE, self.dR, self.grad_clip)
+        self.optimizer_step(lazy_zero=self._last_full and self.accumulate == 1)
         self._grads_zero = True
         return loss
 

@@ -37,14 +37,42 @@ def _flat(t):
     return None if t is None else t.reshape(-1)
 
 
-class AddLossModule(nn.Module):
-    """openkge/trainer.py:32-113."""
+class _TokenPooledLossFn(torch.autograd.Function):
+    """AddLossModule's forward for the token-pooled models: the fused step on the pooled rows + the pooling / batch-norm
+    backward already left the dense gradients of the SUMMED loss in the slots; backward scales them by the upstream
+    scalar and hands them to autograd in the order of `params`."""
 
-    def __init__(self, model, loss, bce_label_smoothing=0.0):
+    @staticmethod
+    def forward(ctx, loss, engine, grads, *params):
+        ctx.engine, ctx.grads = engine, grads
+        return loss.to(torch.float32).reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        alpha = grad_out.reshape(1).to(torch.float32).contiguous()
+        for g in ctx.grads:
+            ctx.engine.scale_(g, alpha)
+        return (None, None, None) + tuple(ctx.grads)
+
+
+class AddLossModule(nn.Module):
+    """openkge/trainer.py:32-113.
+
+    `training_outputs=False` (not in the reference's signature) skips materialising `all_outputs` in TRAINING mode and
+    returns None in its place: the reference's Trainer reads the predictions only in evaluation (trainer.py:258-272), and
+    the (B, N) block is the one thing the fused training kernels never need to write (29.8 MB per step at FB15k-237)."""
+
+    def __init__(self, model, loss, bce_label_smoothing=0.0, training_outputs=True):
         super().__init__()
         self.model = model
         self.loss = loss
         self.bce_label_smoothing = bce_label_smoothing
+        self.training_outputs = training_outputs
+        if getattr(loss, "reduction", "sum") != "sum":
+            # trainer.py:106 sums whatever the loss returns and scripts/train.py builds both losses with reduction='sum';
+            # the fused kernels produce exactly that sum -- any other reduction would be silently different
+            raise NotImplementedError(f"loss.reduction={loss.reduction!r}: the fused path implements reduction='sum' "
+                                      f"(scripts/train.py:92-99)")
 
     def _loss_kind(self):
         if isinstance(self.loss, KLDivLoss):
@@ -63,6 +91,9 @@ class AddLossModule(nn.Module):
         kind = self._loss_kind()
         m = self.model
         eng = m.engine()
+        dev = m.entity_embedding.weight.device
+        token_model = hasattr(m, "entity_token_ids")
+        n_ent, first = m.train_data.entities_size, m.train_data.min_entities_size
         po, sp = inputs
         batch = H.PrefixBatch()
         if po is not None:
@@ -71,29 +102,34 @@ class AddLossModule(nn.Module):
             batch.sp_subj, batch.sp_rel = _flat(sp[0]), _flat(sp[1])
         # candidates: all entities in eval without batch sharing (trainer.py:77-78), else the shared id list
         if batch_shared_entities is None or (not use_batch_shared_entities and not m.training):
-            batch.cand_first = m.train_data.min_entities_size
-            batch.n_cand = m.E.shape[0] - batch.cand_first
+            batch.cand_first = first
+            batch.n_cand = n_ent - batch.cand_first
         else:
             ids = batch_shared_entities.reshape(-1)
-            first = m.train_data.min_entities_size
-            if ids.numel() == m.E.shape[0] - first and not use_batch_shared_entities:
+            if ids.numel() == n_ent - first and not use_batch_shared_entities:
                 batch.cand_first, batch.n_cand = first, int(ids.numel())      # arange(vocab)[offset:] (dataset.py:872)
             else:
                 batch.cand_ids, batch.n_cand = ids, int(ids.numel())
-        if isinstance(labels, tuple):                               # (pos_row, pos_col) coordinates
+        if isinstance(labels, tuple):                               # (pos_row, pos_col) coordinates, sorted by column
             batch.pos_row, batch.pos_col = labels
+            if H.VALIDATE and batch.pos_col.numel() > 1 and bool((batch.pos_col[1:] < batch.pos_col[:-1]).any()):
+                raise ValueError("coordinate labels must be sorted by column (the kernels partition them by candidate tile)")
         else:                                                       # dense (B, N) {0,1} (dataset.py:885-932)
-            batch.pos_row, batch.pos_col = H.positives_from_dense(labels.to(m.E.device))
+            batch.pos_row, batch.pos_col = H.positives_from_dense(labels.to(dev))
+        B, n = batch.B, batch.n_cand
+        want_grad = torch.is_grad_enabled() and m.training
+        all_outputs = None
+        if self.training_outputs or not m.training:
+            all_outputs = torch.empty((B, (n + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :n]
+        smoothing = self.bce_label_smoothing if kind == "bce" else 0.0
+        hook_loss = m.after_batch_loss_hook(epoch) if hasattr(m, "after_batch_loss_hook") else None
+        if token_model:
+            return self._token_result(m, batch, kind, smoothing, want_grad, all_outputs, hook_loss)
         if m.training:
             m.dropout_step += 1
         batch.drop_cand = m.dropout_spec(H.STREAM_CAND)
         batch.drop_po_ent, batch.drop_sp_ent = m.dropout_spec(H.STREAM_PO_ENT), m.dropout_spec(H.STREAM_SP_ENT)
         batch.drop_po_rel, batch.drop_sp_rel = m.dropout_spec(H.STREAM_PO_REL, True), m.dropout_spec(H.STREAM_SP_REL, True)
-        B, n = batch.B, batch.n_cand
-        all_outputs = torch.empty((B, (n + 3) // 4 * 4), dtype=torch.float32, device=m.E.device)[:, :n]
-        smoothing = self.bce_label_smoothing if kind == "bce" else 0.0
-        hook_loss = m.after_batch_loss_hook(epoch) if hasattr(m, "after_batch_loss_hook") else None
-        want_grad = torch.is_grad_enabled() and m.training
         if want_grad:
             g_e, g_r = torch.zeros_like(m.E), torch.zeros_like(m.R)
             loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, g_e, g_r, loss=kind, label_smoothing=smoothing,
@@ -102,6 +138,19 @@ class AddLossModule(nn.Module):
         else:
             loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, None, None, loss=kind, label_smoothing=smoothing,
                                         normalizer=1.0, scores=all_outputs, loss_only=True)
+            result = loss.to(torch.float32).reshape(())
+        return result, hook_loss, all_outputs
+
+    def _token_result(self, m, batch, kind, smoothing, want_grad, all_outputs, hook_loss):
+        """UnigramPooling* models (model.py:716-796): the pooled rows of the batch form two small virtual tables, the
+        fused step runs on them, and the pooling / batch-norm backward deposits dense token-table gradients."""
+        if want_grad:
+            st = m.autograd_step(kind, smoothing)
+            loss = st.forward_backward(batch, normalizer=1.0, scores=all_outputs)
+            params, grads = m.autograd_params_and_grads(st)
+            result = _TokenPooledLossFn.apply(loss, m.engine(), grads, *params)
+        else:
+            loss = m.loss_only(batch, kind, smoothing, all_outputs)
             result = loss.to(torch.float32).reshape(())
         return result, hook_loss, all_outputs
 

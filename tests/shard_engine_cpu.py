@@ -107,6 +107,11 @@ class OracleShardEngine:
         m = X.max(axis=1)
         return torch.from_numpy((m + np.log(np.exp(X - m[:, None]).sum(axis=1))).astype(np.float32))
 
+    def merge_logsumexp(self, parts, out=None):
+        x = _np(parts).astype(np.float64)
+        m = x.max(axis=0)
+        return torch.from_numpy((m + np.log(np.exp(x - m[None, :]).sum(axis=0))).astype(np.float32))
+
     def group_true_scores(self, scores, col0, row_ptr, grp_ptr, ids):
         x, rp, gp, idn = _np(scores), _np(row_ptr), _np(grp_ptr), _np(ids)
         out = np.full(len(gp) - 1, -np.inf, np.float32)
