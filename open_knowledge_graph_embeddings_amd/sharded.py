@@ -6,8 +6,11 @@ Every rank processes the SAME batch of prefixes against ITS OWN slice of the can
 (tensor-parallel over the candidate axis); scores are independent per candidate and the BCE
 loss is separable, so one step needs exactly two small exchanges:
 
-    all-reduce(sum)  [B, d]     masked prefix entity rows (each row is non-zero on its owner); every rank then folds
-                                them with its replicated relation rows into the query block itself
+    all-gather       [cap, d]   the masked prefix entity rows each rank OWNS (cap = the largest per-rank count, padded), when
+                                the batch carries a host-built exchange plan (`make_exchange_plan`: the ids are known on
+                                the host before the batch is uploaded) -- half the bytes of the fallback, an
+    all-reduce(sum)  [B, d]     of the row block that is zero except on each row's owner; every rank then folds the rows
+                                with its replicated relation rows into the query block itself
     all-reduce(sum)  [B, d]     partial query gradients dQ
 (the scalar loss stays a per-rank partial until `reduce_loss()` is called: the reference looks at it every 100 steps)
 
@@ -34,6 +37,44 @@ def shard_range(n_ent, world, rank):
     """Contiguous, equal-sized row ranges (the last one may be shorter)."""
     per = (n_ent + world - 1) // world
     return min(rank * per, n_ent), min((rank + 1) * per, n_ent)
+
+
+class ExchangePlan:
+    """Who owns which prefix entity row of ONE global batch, built on the host from the ids (they exist there before
+    the batch is uploaded: the producer / the synthetic generator made them).
+      cap        rows every rank contributes to the all-gather (the largest per-rank count)
+      owned[r]   int64[cap] batch rows rank r sends: its own rows, padded with rows it does NOT own (zero on that rank)
+      slot       int64[B]   position of batch row b in the gathered [world * cap] block"""
+
+    def __init__(self, cap, owned, slot):
+        self.cap, self.owned, self.slot = cap, owned, slot
+
+
+def make_exchange_plan(po_obj, sp_subj, n_ent, world, device):
+    """po_obj / sp_subj: HOST int arrays of the global batch (po rows first).  Returns None when the all-gather would
+    move more rows than the all-reduce it replaces (very skewed ownership: world * cap > 2 B)."""
+    import numpy as np
+    ent = np.concatenate([np.asarray(po_obj, np.int64).reshape(-1), np.asarray(sp_subj, np.int64).reshape(-1)])
+    B = len(ent)
+    per = (n_ent + world - 1) // world
+    owner = np.minimum(ent // per, world - 1)
+    counts = np.bincount(owner, minlength=world)
+    cap = int(counts.max()) if B else 0
+    if B == 0 or world * cap > 2 * B:
+        return None
+    order = np.argsort(owner, kind="stable")
+    start = np.concatenate([[0], np.cumsum(counts)])
+    slot = np.empty(B, np.int64)
+    owned = []
+    for r in range(world):
+        mine = order[start[r]:start[r + 1]]
+        slot[mine] = r * cap + np.arange(len(mine))
+        pad = cap - len(mine)
+        if pad:
+            others = np.flatnonzero(owner != r)[:1]                  # a row this rank does not own: zero in its block
+            mine = np.concatenate([mine, np.repeat(others, pad)])
+        owned.append(torch.from_numpy(mine.astype(np.int64)).to(device))
+    return ExchangePlan(cap, owned, torch.from_numpy(slot).to(device))
 
 
 class ShardedTrainStep:
@@ -64,6 +105,10 @@ class ShardedTrainStep:
         self.n_cand_local = max(0, self.ent_hi - c_lo)
         self.n_cand_global = n_ent - min_entities_size
         self.shard = H.Shard(self.ent_lo, self.ent_hi, c_lo - min_entities_size)
+        # OKGE_SHARDED_FORCE_EXCHANGE=1: a one-rank group still walks the exchange path (collectives of one rank):
+        # rehearsal of the RCCL calls on a one-GPU box
+        import os
+        self.force_exchange = os.environ.get("OKGE_SHARDED_FORCE_EXCHANGE") == "1"
 
     def _set_dropout(self, batch):
         pe, pr, s, t = self.input_dropout, self.relation_input_dropout, self.seed, self.steps
@@ -73,16 +118,44 @@ class ShardedTrainStep:
         batch.drop_po_rel = H.DropoutSpec(pr, s, H.STREAM_PO_REL, t)
         batch.drop_sp_rel = H.DropoutSpec(pr, s, H.STREAM_SP_REL, t)
 
-    def step(self, batch: H.PrefixBatch):
-        """`batch` is the GLOBAL batch (identical on every rank); 1-vs-all candidates; positives carry global columns."""
+    def _entity_rows(self, batch, plan):
+        """masked prefix entity rows of ALL prefixes on every rank: all-gather of the owned rows (plan) or all-reduce"""
+        eng = self.engine
+        er = eng.encode_entity_rows(self.E, self.R, self.scorer, batch, self.shard)
+        if self.world == 1 and not self.force_exchange:
+            return er
+        if plan is None:
+            dist.all_reduce(er, group=self.group)
+            return er
+        mine = er.index_select(0, plan.owned[self.rank])             # [cap, ld]; padding rows are zero here
+        every = torch.empty((self.world * plan.cap, er.shape[1]), dtype=er.dtype, device=er.device)
+        dist.all_gather_into_tensor(every, mine, group=self.group)
+        er.zero_()
+        er[:batch.B] = every.index_select(0, plan.slot)
+        return er
+
+    def step(self, batch: H.PrefixBatch, plan: ExchangePlan = None):
+        """`batch` is the GLOBAL batch (identical on every rank); 1-vs-all candidates; positives carry global columns.
+        `plan` (make_exchange_plan, optional): exchange 1 as an all-gather of owned rows instead of an all-reduce."""
         if batch.cand_ids is not None:
             raise NotImplementedError("batch-shared sampled candidates are too few to shard: use replicas")
         self.steps += 1
         self._set_dropout(batch)
         eng = self.engine
-        # 1. masked entity rows of the prefixes whose entity lives here; sum over ranks = all rows; fold locally
-        er = eng.encode_entity_rows(self.E, self.R, self.scorer, batch, self.shard)
-        dist.all_reduce(er, group=self.group)
+        if self.world == 1 and isinstance(eng, H.HotPath) and not self.force_exchange:
+            # one rank owns everything: the fused single-device call (no slab reduction, no exchange buffers)
+            local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
+                                  pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=self.cand_first_local,
+                                  n_cand=self.n_cand_local, drop_cand=batch.drop_cand, drop_po_ent=batch.drop_po_ent,
+                                  drop_sp_ent=batch.drop_sp_ent, drop_po_rel=batch.drop_po_rel, drop_sp_rel=batch.drop_sp_rel)
+            eng.forward_backward(self.E, self.R, self.scorer, local, self.dE, self.dR, loss=self.loss,
+                                 label_smoothing=self.label_smoothing, normalizer=float(batch.B) * float(self.n_cand_global),
+                                 loss_out=self.loss_out, grads_zero=True)
+            eng.adagrad2(self.E, self.dE, self.sumE, self.R, self.dR, self.sumR, self.lr, self.weight_decay, self.eps,
+                         zero_grad=True)
+            return self.loss_out
+        # 1. masked entity rows of the prefixes whose entity lives here -> all rows everywhere; fold locally
+        er = self._entity_rows(batch, plan)
         qe = (eng.fold_queries(self.E, self.R, self.scorer, batch, er), er)
         # 2. local candidates: loss partial, local entity gradients, partial query gradients
         local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
@@ -99,7 +172,8 @@ class ShardedTrainStep:
                         loss=self.loss, label_smoothing=self.label_smoothing,
                         normalizer=float(batch.B) * float(self.n_cand_global), loss_out=self.loss_out, grads_zero=True,
                         row_lse=row_lse)
-        dist.all_reduce(dq, group=self.group)
+        if self.world > 1 or self.force_exchange:
+            dist.all_reduce(dq, group=self.group)
         # 3. chain rule: entity rows by their owner, relation rows everywhere (identical)
         eng.prefix_backward(self.E, self.R, self.scorer, batch, self.shard, dq, qe[1], self.dE, self.dR)
         # 4. dense Adagrad on the local entity rows and on the replicated relation table
@@ -138,7 +212,8 @@ class ShardedEvaluator:
     def local_scores(self, batch: H.PrefixBatch):
         eng = self.engine
         er = eng.encode_entity_rows(self.E, self.R, self.scorer, batch, self.shard)
-        dist.all_reduce(er, group=self.group)
+        if self.world > 1:
+            dist.all_reduce(er, group=self.group)
         qe = (eng.fold_queries(self.E, self.R, self.scorer, batch, er), er)
         local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
                               cand_first=self.cand_first_local, n_cand=self.n_cand_local)
@@ -186,4 +261,44 @@ class ReplicaTrainStep(FusedTrainStep):
         self.optimizer_step()
         self._grads_zero = True
         loss_work.wait()
+        return loss
+
+
+class ReplicaStep:
+    """Data-parallel replicas around ANY step object that keeps dense gradients in persistent tensors -- used for the
+    token-pooled models (BASELINE configs[4]: batch-shared candidate lists of a few thousand ids are too short to shard;
+    the token tables are small enough to replicate).  Protocol, per step:
+        inner.forward_backward(batch, normalizer * world)       own batch, own dropout stream; gradients of the mean
+        ONE all-reduce(sum) over a flat buffer [gradients | batch-norm running statistics]
+        running statistics /= world (every replica normalised with its own batch: the average keeps them identical)
+        inner.optimizer_step()                                  the same update everywhere: replicas never drift
+    `inner` must expose grad_tensors() / stat_tensors() (lists of tensors), rebind(list, list) to accept views into the
+    flat buffer, forward_backward(batch, normalizer) and optimizer_step()."""
+
+    def __init__(self, inner, group=None):
+        self.inner, self.group = inner, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        grads, stats = inner.grad_tensors(), inner.stat_tensors()
+        sizes = [(t.numel() + 3) // 4 * 4 for t in grads + stats]                # 16-byte aligned sections
+        dev, dt = grads[0].device, grads[0].dtype
+        self.flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+        views, off = [], 0
+        for t, n in zip(grads + stats, sizes):
+            v = self.flat[off:off + t.numel()].view_as(t)
+            v.copy_(t)
+            views.append(v)
+            off += n
+        self._n_grad = sum(sizes[:len(grads)])
+        inner.rebind(views[:len(grads)], views[len(grads):])
+        inner.seed = getattr(inner, "seed", 0) + 1000003 * self.rank             # independent dropout masks per replica
+
+    def step(self, batch, normalizer=None):
+        if normalizer is None:
+            normalizer = float(batch.B) * float(batch.n_candidates)
+        loss = self.inner.forward_backward(batch, normalizer * self.world)
+        if self.world > 1:
+            dist.all_reduce(self.flat, group=self.group)
+            self.flat[self._n_grad:].mul_(1.0 / self.world)
+            dist.all_reduce(loss, group=self.group)
+        self.inner.optimizer_step()
         return loss

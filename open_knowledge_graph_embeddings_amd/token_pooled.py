@@ -150,6 +150,30 @@ class TokenPooledTrainStep:
                 out += [sl.bn, sl.d_bn, sl.sum_bn, sl.running_mean, sl.running_var]
         return out
 
+    # -- sharded.ReplicaStep protocol: gradients / running statistics as views into one flat exchange buffer ---------
+    def grad_tensors(self):
+        out = []
+        for sl in (self.entity, self.relation):
+            out.append(sl.dW)
+            if sl.bn is not None:
+                out.append(sl.d_bn)
+        return out
+
+    def stat_tensors(self):
+        out = []
+        for sl in (self.entity, self.relation):
+            if sl.bn is not None:
+                out += [sl.running_mean, sl.running_var]
+        return out
+
+    def rebind(self, grads, stats):
+        gi, si = iter(grads), iter(stats)
+        for sl in (self.entity, self.relation):
+            sl.dW = next(gi)
+            if sl.bn is not None:
+                sl.d_bn = next(gi)
+                sl.running_mean, sl.running_var = next(si), next(si)
+
     def _buffers(self, n_ent_rows, n_rel_rows):
         d = self.entity.d
         if n_ent_rows > self._rows or n_rel_rows > getattr(self, "_rrows", 0):

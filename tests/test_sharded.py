@@ -100,7 +100,7 @@ def to_batch(b, dev):
 
 
 # ------------------------------------------------------------------------------------------- CPU, gloo, 2 ranks
-def _worker(rank, world, port, outdir, nsteps, loss):
+def _worker(rank, world, port, outdir, nsteps, loss, use_plan=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -119,8 +119,12 @@ def _worker(rank, world, port, outdir, nsteps, loss):
     st = ShardedTrainStep(torch.from_numpy(E[lo:hi].copy()), torch.from_numpy(R.copy()), SCORER, N_ENT, lr=LR,
                           input_dropout=P_DROP, seed=SEED, engine=OracleShardEngine(), loss=loss)
     losses = []
+    from open_knowledge_graph_embeddings_amd.sharded import make_exchange_plan
     for step in range(1, nsteps + 1):
-        st.step(to_batch(problem(step), "cpu"))
+        pb = problem(step)
+        plan = make_exchange_plan(pb["po_obj"], pb["sp_subj"], N_ENT, world, "cpu") if use_plan else None
+        assert not use_plan or plan is not None
+        st.step(to_batch(pb, "cpu"), plan=plan)
         losses.append(float(st.reduce_loss()[0]))
     # checkpoint interop: shards gathered into the reference's state-dict layout, then scattered back
     from open_knowledge_graph_embeddings_amd.checkpoint import load_reference_checkpoint, save_checkpoint
@@ -135,15 +139,17 @@ def _worker(rank, world, port, outdir, nsteps, loss):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,loss", [(2, "bce"), (3, "bce"), (2, "kl")])
-def test_sharded_exchange_protocol_gloo(world, loss):
+@pytest.mark.parametrize("world,loss,use_plan", [(2, "bce", False), (3, "bce", False), (2, "kl", False), (3, "bce", True),
+                                                 (2, "kl", True)])
+def test_sharded_exchange_protocol_gloo(world, loss, use_plan):
+    """use_plan: exchange 1 as an all-gather of the rows each rank owns (host-built plan) instead of an all-reduce"""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     nsteps = 2
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker, args=(world, port, outdir, nsteps, loss), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, outdir, nsteps, loss, use_plan), nprocs=world, join=True)
         parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
     E_ref, R_ref, losses_ref = oracle_reference(nsteps, loss=ko.LOSS_KL if loss == "kl" else ko.LOSS_BCE)
     ranks_ref = oracle_ranks(eval_problem())
@@ -226,6 +232,99 @@ def test_replica_step_gloo():
     close = np.isclose(parts[0]["E"], E, rtol=2e-4, atol=2e-5)
     assert close.mean() > 0.999 and np.abs(parts[0]["E"] - E).max() < 5e-3
     np.testing.assert_allclose(parts[0]["R"], R, rtol=2e-4, atol=2e-5)
+
+
+class _ToyInner:
+    """the smallest object with the ReplicaStep protocol: gradient = batch-dependent tensor, one running statistic"""
+
+    def __init__(self, rank):
+        self.w = torch.zeros(5)
+        self.g, self.g2 = torch.zeros(5), torch.zeros(3)
+        self.stat = torch.full((2,), float(rank))
+        self.seed = 7
+
+    def grad_tensors(self):
+        return [self.g, self.g2]
+
+    def stat_tensors(self):
+        return [self.stat]
+
+    def rebind(self, grads, stats):
+        self.g, self.g2 = grads
+        (self.stat,) = stats
+
+    def forward_backward(self, batch, normalizer):
+        self.g.copy_(batch["x"] / normalizer)
+        self.g2.fill_(1.0 / normalizer)
+        self.stat += 1.0
+        return torch.tensor([float(batch["x"].sum()) / normalizer], dtype=torch.float64)
+
+    def optimizer_step(self):
+        self.w -= self.g
+        self.g.zero_()
+        self.g2.zero_()
+
+
+def _replica_step_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    inner = _ToyInner(rank)
+    st = ReplicaStep(inner)
+    assert inner.seed == 7 + 1000003 * rank
+
+    class B:                                                    # noqa: D401  (duck-typed batch)
+        B, n_candidates = 2, 5
+
+        def __getitem__(self, k):
+            return torch.arange(5, dtype=torch.float32) * (rank + 1)
+    loss = st.step(B())
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=inner.w.numpy(), stat=inner.stat.numpy(), loss=loss.numpy())
+    dist.destroy_process_group()
+
+
+def test_replica_step_protocol_gloo():
+    """ReplicaStep (used for the token-pooled models): summed gradients of the mean loss, averaged running statistics,
+    identical parameters on every rank"""
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_replica_step_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
+    x = np.arange(5, dtype=np.float32)
+    norm = 2 * 5 * world
+    np.testing.assert_allclose(parts[0]["w"], -(x * 1 + x * 2) / norm, rtol=1e-6)
+    np.testing.assert_array_equal(parts[0]["w"], parts[1]["w"])
+    np.testing.assert_allclose(parts[0]["stat"], [(0 + 1 + 1 + 1) / 2.0] * 2)        # mean of (rank + 1) over the ranks
+    np.testing.assert_array_equal(parts[0]["stat"], parts[1]["stat"])
+    np.testing.assert_allclose(parts[0]["loss"], [(x.sum() * 1 + x.sum() * 2) / norm])
+
+
+def test_exchange_plan():
+    from open_knowledge_graph_embeddings_amd.sharded import make_exchange_plan, shard_range
+    rng = np.random.default_rng(0)
+    n_ent, world = 1000, 4
+    po, sp = rng.integers(2, n_ent, 40), rng.integers(2, n_ent, 24)
+    plan = make_exchange_plan(po, sp, n_ent, world, "cpu")
+    ent = np.concatenate([po, sp])
+    assert plan.cap * world < 2 * len(ent)
+    seen = np.zeros(len(ent), bool)
+    for r in range(world):
+        lo, hi = shard_range(n_ent, world, r)
+        own = plan.owned[r].numpy()
+        n_own = int(((ent >= lo) & (ent < hi)).sum())
+        assert ((ent[own[:n_own]] >= lo) & (ent[own[:n_own]] < hi)).all()            # its own rows first ...
+        assert not ((ent[own[n_own:]] >= lo) & (ent[own[n_own:]] < hi)).any()        # ... padded with rows it does not own
+        for k, b in enumerate(own[:n_own]):
+            assert plan.slot[b] == r * plan.cap + k
+            seen[b] = True
+    assert seen.all()
+    # all prefixes on one shard: the all-gather would move world x B rows -> fall back to the all-reduce
+    assert make_exchange_plan(np.full(40, 5), np.full(24, 7), n_ent, world, "cpu") is None
 
 
 def test_shard_ranges_cover_table():
@@ -394,6 +493,158 @@ def test_replica_step_one_rank_equals_fused_step(okge_lib):
         torch.cuda.synchronize()
         # duplicate candidate ids accumulate with atomics: same sums, run-dependent order
         assert abs(float(a.loss_out[0]) - float(f.loss_out[0])) <= 1e-6 * abs(float(f.loss_out[0]))
+        np.testing.assert_allclose(a.E.cpu().numpy(), f.E.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(a.R.cpu().numpy(), f.R.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replica_step_token_pooled_one_rank(okge_lib):
+    """sharded.ReplicaStep around TokenPooledTrainStep (BASELINE configs[4]'s multi-GPU mode) with a one-rank group ==
+    the plain step: the gradients and running statistics live in the flat exchange buffer"""
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        rng = np.random.default_rng(3)
+        vocab, n_ids, L, d = 90, 150, 5, 64
+        We = (rng.standard_normal((vocab, d)) * 0.3).astype(np.float32)
+        Wr = (rng.standard_normal((40, d)) * 0.3).astype(np.float32)
+        te = rng.integers(0, vocab, (n_ids, L)).astype(np.int32)
+        tr = rng.integers(0, 40, (30, L)).astype(np.int32)
+        t = lambda x: torch.from_numpy(x).cuda()      # noqa: E731
+
+        def make():
+            e = TokenSlot(t(We.copy()), t(te), "sum", True, torch.linspace(0.5, 1.5, d).cuda(), torch.zeros(d).cuda())
+            r = TokenSlot(t(Wr.copy()), t(tr), "sum", True, torch.linspace(0.5, 1.5, d).cuda(), torch.zeros(d).cuda())
+            return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=0.0, seed=5)
+        plain, inner = make(), make()
+        rep = ReplicaStep(inner)
+        inner.seed = plain.seed                                   # rank 0 offsets the seed by 0 anyway
+        for step in range(3):
+            r2 = np.random.default_rng(50 + step)
+            b, nc = 24, 64
+            cand = r2.permutation(np.arange(2, n_ids))[:nc].astype(np.int32)
+            rows = np.arange(2 * b, dtype=np.int32)
+            cols = np.sort(r2.integers(0, nc, 2 * b)).astype(np.int32)
+            mk = lambda: PrefixBatch(po_rel=t(r2.integers(2, 30, b).astype(np.int32)), po_obj=t(r2.integers(2, n_ids, b).astype(np.int32)),  # noqa: E731
+                                     sp_subj=t(r2.integers(2, n_ids, b).astype(np.int32)), sp_rel=t(r2.integers(2, 30, b).astype(np.int32)),
+                                     pos_row=t(rows), pos_col=t(cols), cand_ids=t(cand))
+            batch = mk()
+            la = float(plain.step(batch)[0])
+            lb = float(rep.step(batch)[0])
+            assert abs(la - lb) <= 1e-6 * abs(la)
+        torch.cuda.synchronize()
+        for a, b_ in ((plain.entity, inner.entity), (plain.relation, inner.relation)):
+            np.testing.assert_allclose(a.W.cpu().numpy(), b_.W.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(a.bn.cpu().numpy(), b_.bn.cpu().numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(a.running_mean.cpu().numpy(), b_.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert inner.entity.dW.data_ptr() >= rep.flat.data_ptr() and float(rep.flat.abs().sum()) >= 0
+    finally:
+        dist.destroy_process_group()
+
+
+def _nccl_worker(rank, world, port, outdir, nsteps, loss):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.sharded import ShardedEvaluator, ShardedTrainStep, make_exchange_plan, shard_range
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as e:                                       # RCCL could not come up on this box: not a numerics failure
+        open(os.path.join(outdir, f"rank{rank}.skip"), "w").write(repr(e))
+        return
+    E, R = tables()
+    lo, hi = shard_range(N_ENT, world, rank)
+    t = lambda a: torch.from_numpy(a).to(dev)      # noqa: E731
+    ev = ShardedEvaluator(t(E[lo:hi].copy()), t(R.copy()), SCORER, N_ENT)
+    eb = eval_problem()
+    ranks = ev.ranks(to_batch(eb, dev), t(eb["filt_ptr"]), t(eb["filt_col"]), t(eb["row_ptr"]), t(eb["grp_ptr"]), t(eb["ids"]))
+    st = ShardedTrainStep(t(E[lo:hi].copy()), t(R.copy()), SCORER, N_ENT, lr=LR, input_dropout=P_DROP, seed=SEED, loss=loss)
+    losses = []
+    for step in range(1, nsteps + 1):
+        pb = problem(step)
+        plan = make_exchange_plan(pb["po_obj"], pb["sp_subj"], N_ENT, world, dev) if step % 2 == 0 else None
+        st.step(to_batch(pb, dev), plan=plan)
+        losses.append(float(st.reduce_loss()[0]))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), E=st.E.cpu().numpy(), R=st.R.cpu().numpy(), lo=lo, hi=hi,
+             losses=np.asarray(losses), ranks=ranks.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss", ["bce", "kl"])
+def test_sharded_step_two_ranks_rccl(okge_lib, loss):
+    """The real thing: two processes, two GPUs, RCCL -- entity table row-sharded, both exchanges (all-gather plan on even
+    steps, all-reduce on odd ones), sharded evaluation.  Skipped on one-GPU boxes; the first box with two or more runs it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    world, nsteps = 2, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_nccl_worker, args=(world, port, outdir, nsteps, loss), nprocs=world, join=True)
+        skips = [f for f in os.listdir(outdir) if f.endswith(".skip")]
+        if skips:
+            pytest.skip("RCCL did not initialise here: " + open(os.path.join(outdir, skips[0])).read()[:200])
+        parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
+    E_ref, R_ref, losses_ref = oracle_reference(nsteps, loss=ko.LOSS_KL if loss == "kl" else ko.LOSS_BCE)
+    ranks_ref = oracle_ranks(eval_problem())
+    for p in parts:
+        assert (p["ranks"] != ranks_ref).mean() < 0.01 and np.abs(p["ranks"] - ranks_ref).max() <= 1
+    np.testing.assert_array_equal(parts[0]["ranks"], parts[1]["ranks"])
+    E = np.concatenate([p["E"] for p in parts])
+    close = np.isclose(E, E_ref, rtol=1e-3, atol=1e-4)
+    assert close.mean() > 0.999 and np.abs(E - E_ref).max() < 5e-3
+    for p in parts:
+        np.testing.assert_allclose(p["R"], R_ref, rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(p["losses"], losses_ref, rtol=3e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss", ["bce", "kl"])
+def test_sharded_step_rccl_one_rank_rehearsal(okge_lib, loss, monkeypatch):
+    """the exchange path (all-gather plan / all-reduce, cross-rank log-sum-exp, dQ all-reduce) through the RCCL backend
+    with a one-rank group: every collective call the multi-GPU run makes is issued and must leave the step equal to the
+    fused single-device step"""
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep, make_exchange_plan
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+    monkeypatch.setenv("OKGE_SHARDED_FORCE_EXCHANGE", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        E, R = tables()
+        a = ShardedTrainStep(torch.from_numpy(E.copy()).cuda(), torch.from_numpy(R.copy()).cuda(), SCORER, N_ENT, lr=LR,
+                             input_dropout=P_DROP, seed=SEED, loss=loss)
+        assert a.force_exchange
+        f = FusedTrainStep(torch.from_numpy(E.copy()).cuda(), torch.from_numpy(R.copy()).cuda(), SCORER, lr=LR,
+                           input_dropout=P_DROP, seed=SEED, loss=loss)
+        for step in range(1, 4):
+            pb = problem(step)
+            plan = make_exchange_plan(pb["po_obj"], pb["sp_subj"], N_ENT, 1, dev) if step % 2 == 0 else None
+            la = float(a.step(to_batch(pb, "cuda:0"), plan=plan)[0])
+            lf = float(f.step(to_batch(pb, "cuda:0"))[0])
+            assert abs(la - lf) <= 2e-6 * abs(lf)
         np.testing.assert_allclose(a.E.cpu().numpy(), f.E.cpu().numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(a.R.cpu().numpy(), f.R.cpu().numpy(), rtol=1e-4, atol=1e-5)
     finally:
