@@ -127,18 +127,21 @@ def run_olp(world, rank, dev, dist, barrier, steps=6, warmup=2):
 
     Rt = table(0, w.n_rel, w.d, 99)
     if world > 1:
-        from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep, shard_range
+        from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep, make_exchange_plan, shard_range
         lo, hi = shard_range(w.n_ent, world, rank)
         step = ShardedTrainStep(table(lo, hi, w.d, 7), Rt, w.scorer, w.n_ent, lr=w.lr, loss=w.loss, seed=1234)
+        plans = [make_exchange_plan(hb["po_obj"], hb["sp_subj"], w.n_ent, world, dev) for hb in host_batches]   # Zipf ids: may be None
+        run = lambda i: step.step(batches[i % 4], plan=plans[i % 4])           # noqa: E731
     else:
         step = FusedTrainStep(table(0, w.n_ent, w.d, 7), Rt, w.scorer, loss=w.loss, lr=w.lr, seed=1234)
+        run = lambda i: step.step(batches[i % 4])                               # noqa: E731
     for i in range(warmup):
-        step.step(batches[i % 4])
+        run(i)
     barrier()
     t0 = time.perf_counter()
     triples = 0
     for i in range(steps):
-        step.step(batches[i % 4])
+        run(i)
         triples += n_pos[i % 4]
     barrier()
     el = time.perf_counter() - t0
@@ -207,6 +210,9 @@ def main():
         Et, Rt = torch.from_numpy(E[lo:hi].copy()).to(dev), torch.from_numpy(R).to(dev)
         step = ShardedTrainStep(Et, Rt, w.scorer, w.n_ent, lr=w.lr, loss=w.loss, input_dropout=w.input_dropout, seed=1234)
         batches = [to_dev_batch(hb, wg, dev) for hb in host_batches]
+        # exchange 1 as an all-gather of the rows each rank owns: the plan is host work on ids the host already has
+        from open_knowledge_graph_embeddings_amd.sharded import make_exchange_plan
+        plans = [make_exchange_plan(hb["po_obj"], hb["sp_subj"], w.n_ent, world, dev) for hb in host_batches]
         w_run = wg
     else:
         host_batches = [synthetic.make_batch(w, seed=1234 + i) for i in range(N_BATCHES)]
@@ -226,6 +232,8 @@ def main():
     # replayed vs 0.144 launched -- graph nodes dispatch with wider gaps than back-to-back stream launches and the
     # host keeps ahead of a 0.15 ms step anyway -- so the default is plain launches.
     run = lambda i: step.step(batches[i % N_BATCHES])                       # noqa: E731
+    if sharded:
+        run = lambda i: step.step(batches[i % N_BATCHES], plan=plans[i % N_BATCHES])   # noqa: E731
     if not sharded and os.environ.get("OKGE_BENCH_GRAPH", "0") == "1":
         from open_knowledge_graph_embeddings_amd.train_step import GraphedTrainStep
         g0 = GraphedTrainStep(step, batches[0], pos_capacity=batches[0].nnz)
@@ -255,7 +263,7 @@ def main():
         eng.timing(True)
     ksteps = min(args.steps, 50)
     for i in range(ksteps):
-        step.step(batches[i % N_BATCHES])
+        run(i)
     barrier()
     if rank == 0:
         per_kernel = eng.timing_collect()

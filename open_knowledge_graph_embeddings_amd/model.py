@@ -8,8 +8,11 @@ ids are int32 ``(b, 1)`` (or ``(N,)`` for candidates), scores come back ``(b, N)
 * every arithmetic step runs in libokge_hip.so (no ATen math); the methods return plain tensors without an
   autograd graph.  Gradients are produced by ``trainer.AddLossModule`` (fused forward + loss + backward), which
   is how the reference's Trainer consumes the model (openkge/trainer.py:142,206-234);
-* only the configuration the fused path covers is accepted: lookup embedder with batch_norm / projection /
-  normalize / l2_reg off and dense gradients.  Anything else raises NotImplementedError at construction;
+* the fused path (gather + dropout inside the tile kernels) covers the lookup embedder with batch_norm / projection /
+  normalize / l2_reg off -- every BASELINE config.  With one of those `_encode` variants on (model.py:463-479) the
+  embedder FALLS THROUGH to torch for the encode (the reference's own op sequence, differentiable) and the encoded rows
+  go through the HIP scorer / loss / backward as two small virtual tables (trainer.AddLossModule); sparse gradients and
+  the relation projection of the non-"Simple" embedder raise NotImplementedError at construction;
 * the two dropouts the reference applies in sequence (input_dropout, dropout; model.py:461-470) draw from a
   counter-based Philox stream instead of torch's global generator.
 """
@@ -64,6 +67,7 @@ class RelationScorer(RelationModel):
         if not prefix:
             return self.triple_score(subj, rel, obj)
         eng = self.engine()
+        subj, rel, obj = subj.detach(), rel.detach(), obj.detach()      # inference helper: gradients come from AddLossModule
         rel = rel.reshape(-1, rel.shape[-1]).contiguous()
         b = rel.shape[0]
         ar = torch.arange(b, dtype=torch.int32, device=rel.device)
@@ -103,24 +107,44 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
                  project_relation=True, project_relation_activation=None, sparse=False, init_std=0.01,
                  batch_norm=False, l2_reg=0, seed=0):
         super().__init__()
-        unsupported = dict(normalize=normalize, project_entity=project_entity, project_relation=project_relation,
-                           sparse=sparse, batch_norm=batch_norm, l2_reg=l2_reg)
-        bad = {k: v for k, v in unsupported.items() if v}
-        if bad or (entity_embedding_size not in (None, entity_slot_size)) or \
-                (relation_embedding_size not in (None, entity_slot_size)):
-            raise NotImplementedError(f"outside the fused lookup path (openkge/model.py:463-479 variants): {bad}")
+        if sparse or project_relation:
+            raise NotImplementedError("outside the lookup path: sparse gradients / relation projection (openkge/model.py:391-409)")
+        if relation_slot_size is None or relation_slot_size <= 0:
+            relation_slot_size = entity_slot_size
+        e_size = entity_slot_size if entity_embedding_size is None else entity_embedding_size
+        r_size = relation_slot_size if relation_embedding_size is None else relation_embedding_size
+        if r_size != entity_slot_size or (e_size != entity_slot_size and not project_entity):
+            raise NotImplementedError("embedding sizes other than the slot size need the matching projection")
         self.train_data = train_data
         self.slot_size = entity_slot_size
-        self.entity_embedding = torch.nn.Embedding(train_data.entities_size, entity_slot_size, padding_idx=PAD)
-        self.relation_embedding = torch.nn.Embedding(train_data.relations_size, entity_slot_size, padding_idx=PAD)
+        # module construction order = the reference's (model.py:389-440): identical parameters from identical seeds
+        self.entity_embedding = torch.nn.Embedding(train_data.entities_size, e_size, padding_idx=PAD)
+        self.relation_embedding = torch.nn.Embedding(train_data.relations_size, r_size, padding_idx=PAD)
+        self.project_entity, self.project_relation = bool(project_entity), False
+        if project_entity:
+            act = lambda: [getattr(torch.nn, project_entity_activation)()] if project_entity_activation else []   # noqa: E731
+            subj_layer = torch.nn.Linear(entity_slot_size, entity_slot_size, bias=False)
+            obj_layer = torch.nn.Linear(entity_slot_size, entity_slot_size, bias=False)
+            torch.nn.init.xavier_normal_(subj_layer.weight.data)
+            torch.nn.init.xavier_normal_(obj_layer.weight.data)
+            self.subj_projection = torch.nn.Sequential(subj_layer, *act())
+            self.obj_projection = torch.nn.Sequential(obj_layer, *act())
         torch.nn.init.normal_(self.entity_embedding.weight.data, std=init_std)       # model.py:429-430
         torch.nn.init.normal_(self.relation_embedding.weight.data, std=init_std)
         self.dropout = dropout
         self.input_dropout = input_dropout
         self.relation_dropout = dropout if relation_dropout is None else relation_dropout          # model.py:434-435
         self.relation_input_dropout = input_dropout if relation_input_dropout is None else relation_input_dropout
-        self.project_entity = self.project_relation = self.batch_norm = False
-        self.normalize, self.l2_reg = '', 0
+        self.batch_norm = bool(batch_norm)
+        if self.batch_norm:
+            self.bn_e = torch.nn.BatchNorm1d(e_size)
+            self.bn_r = torch.nn.BatchNorm1d(r_size)
+        self.normalize, self.l2_reg = normalize or '', l2_reg
+        self._l2_reg_hook = None
+        # any _encode variant on: the embedder falls through to torch (module docstring)
+        self.encode_in_torch = bool(self.batch_norm or self.project_entity or self.normalize or self.l2_reg)
+        if self.normalize not in ('', 'norm'):
+            raise NotImplementedError(f"normalize={normalize!r}")
         self.dropout_seed = seed
         self.dropout_step = 0          # advanced once per training batch by AddLossModule
         self._engine = None
@@ -152,10 +176,46 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
         return H.DropoutSpec(p, self.dropout_seed, stream, self.dropout_step)
 
     def after_batch_loss_hook(self, epoch):
-        return None                       # l2_reg hook (model.py:447-453) is off on this path
+        """model.py:447-453"""
+        if self.training and self.l2_reg > 0:
+            result, self._l2_reg_hook = self._l2_reg_hook, None
+            return result
+        return None
 
     # -- RelationEmbedder protocol ------------------------------------------------------------------
-    def _encode(self, table, slot_item, stream, relation, lookup=True):
+    def _encode_torch(self, slot_item, embedding, project, input_dropout, dropout, batch_norm, lookup=True):
+        """model.py:455-480, op for op (ATen on the GPU, differentiable): the fall-through for embedder variants"""
+        F = torch.nn.functional
+        if lookup:
+            rows = embedding(slot_item.reshape(-1).long())
+        else:
+            rows = slot_item
+        if input_dropout > 0:
+            rows = F.dropout(rows, p=input_dropout, training=self.training)
+        if self.batch_norm:
+            rows = batch_norm(rows)
+        if project is not None:
+            rows = project(rows)
+        if self.normalize == 'norm':
+            rows = F.normalize(rows)
+        if dropout > 0:
+            rows = F.dropout(rows, p=dropout, training=self.training)
+        if self.training and self.l2_reg > 0:
+            hook = rows
+            if self.dropout > 0:
+                hook = hook / self.dropout
+            hook = self.l2_reg * hook.abs().pow(3).sum()
+            self._l2_reg_hook = hook if self._l2_reg_hook is None else self._l2_reg_hook + hook
+        return rows
+
+    def _encode(self, table, slot_item, stream, relation, lookup=True, which=None):
+        if self.encode_in_torch:
+            if relation:
+                return self._encode_torch(slot_item, self.relation_embedding, None, self.relation_input_dropout,
+                                          self.relation_dropout, self.bn_r if self.batch_norm else None, lookup)
+            proj = (self.subj_projection if which == "subj" else self.obj_projection) if self.project_entity else None
+            return self._encode_torch(slot_item, self.entity_embedding, proj, self.input_dropout, self.dropout,
+                                      self.bn_e if self.batch_norm else None, lookup)
         eng = self.engine()
         if not lookup:                    # model.py:459-460: already rows, only dropout applies
             rows = slot_item.contiguous()
@@ -163,23 +223,26 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
         return eng.encode_rows(table, slot_item.reshape(-1), drop=self.dropout_spec(stream, relation))
 
     def encode_subj(self, subj, lookup=True):
-        return self._encode(self.E, subj, H.STREAM_SP_ENT, False, lookup)
+        return self._encode(self.E, subj, H.STREAM_SP_ENT, False, lookup, which="subj")
 
     def encode_obj(self, obj, lookup=True):
-        return self._encode(self.E, obj, H.STREAM_PO_ENT, False, lookup)
+        return self._encode(self.E, obj, H.STREAM_PO_ENT, False, lookup, which="obj")
 
     def encode_rel(self, rel, lookup=True):
         return self._encode(self.R, rel, H.STREAM_SP_REL, True, lookup)
 
-    def _get_all(self, table, min_size, stream, relation):
+    def _get_all(self, table, min_size, stream, relation, which=None):
+        if self.encode_in_torch:           # model.py:512-514: encode(weight[min_size:], lookup=False)
+            w = (self.relation_embedding if relation else self.entity_embedding).weight[min_size:].contiguous()
+            return self._encode(None, w, stream, relation, lookup=False, which=which)
         return self.engine().encode_rows(table, None, min_size, table.shape[0] - min_size,
                                          self.dropout_spec(stream, relation))
 
     def get_all_subj(self):
-        return self._get_all(self.E, self.train_data.min_entities_size, H.STREAM_CAND, False)
+        return self._get_all(self.E, self.train_data.min_entities_size, H.STREAM_CAND, False, "subj")
 
     def get_all_obj(self):
-        return self._get_all(self.E, self.train_data.min_entities_size, H.STREAM_CAND, False)
+        return self._get_all(self.E, self.train_data.min_entities_size, H.STREAM_CAND, False, "obj")
 
     def get_all_rel(self):
         return self._get_all(self.R, self.train_data.min_relations_size, H.STREAM_SP_REL, True)
@@ -202,6 +265,14 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
     # -- fused prefix scoring (ids in, scores out) -----------------------------------------------------
     def _prefix_score(self, batch: H.PrefixBatch, many=None):
         eng = self.engine()
+        if self.encode_in_torch:           # variants: torch encode (model.py:52-74's own call order), HIP scorer
+            if batch.sp_subj is not None:
+                subj, rel = self.encode_subj(batch.sp_subj), self.encode_rel(batch.sp_rel)
+                return self._score(subj, rel, self.get_all_obj() if many is None else many, prefix=True, sp=True, po=False)
+            if many is None:
+                many = self.get_all_subj()
+            rel, obj = self.encode_rel(batch.po_rel), self.encode_obj(batch.po_obj)
+            return self._score(many, rel, obj, prefix=True, sp=False, po=True)
         if many is None:                   # all entities with id >= min_entities_size (model.py:512-523)
             batch.cand_first = self.train_data.min_entities_size
             batch.n_cand = self.E.shape[0] - batch.cand_first

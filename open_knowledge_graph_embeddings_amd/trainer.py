@@ -37,6 +37,29 @@ def _flat(t):
     return None if t is None else t.reshape(-1)
 
 
+class _VirtualTablesLossFn(torch.autograd.Function):
+    """Loss of already ENCODED rows (embedder variants that fall through to torch): the rows of one batch form two small
+    virtual tables -- EV = [candidates | po objects | sp subjects], RV = [po relations | sp relations] -- the fused HIP
+    step runs on them without dropout (it was applied by the encode) and returns the dense row gradients, which autograd
+    carries back through the projection / batch-norm / normalisation into the parameters."""
+
+    @staticmethod
+    def forward(ctx, EV, RV, engine, scorer, vb, kind, smoothing, scores):
+        EVc, RVc = EV.detach().contiguous(), RV.detach().contiguous()
+        dEV, dRV = torch.zeros_like(EVc), torch.zeros_like(RVc)
+        loss = engine.forward_backward(EVc, RVc, scorer, vb, dEV, dRV, loss=kind, label_smoothing=smoothing, normalizer=1.0,
+                                       scores=scores, grads_zero=True)
+        ctx.engine, ctx.grads = engine, (dEV, dRV)
+        return loss.to(torch.float32).reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        alpha = grad_out.reshape(1).to(torch.float32).contiguous()
+        for g in ctx.grads:
+            ctx.engine.scale_(g, alpha)
+        return ctx.grads[0], ctx.grads[1], None, None, None, None, None, None
+
+
 class _TokenPooledLossFn(torch.autograd.Function):
     """AddLossModule's forward for the token-pooled models: the fused step on the pooled rows + the pooling / batch-norm
     backward already left the dense gradients of the SUMMED loss in the slots; backward scales them by the upstream
@@ -68,7 +91,7 @@ class AddLossModule(nn.Module):
         self.loss = loss
         self.bce_label_smoothing = bce_label_smoothing
         self.training_outputs = training_outputs
-        if getattr(loss, "reduction", "sum") != "sum":
+        if isinstance(loss, (BCEWithLogitsLoss, KLDivLoss)) and loss.reduction != "sum":
             # trainer.py:106 sums whatever the loss returns and scripts/train.py builds both losses with reduction='sum';
             # the fused kernels produce exactly that sum -- any other reduction would be silently different
             raise NotImplementedError(f"loss.reduction={loss.reduction!r}: the fused path implements reduction='sum' "
@@ -125,6 +148,9 @@ class AddLossModule(nn.Module):
         hook_loss = m.after_batch_loss_hook(epoch) if hasattr(m, "after_batch_loss_hook") else None
         if token_model:
             return self._token_result(m, batch, kind, smoothing, want_grad, all_outputs, hook_loss)
+        if getattr(m, "encode_in_torch", False):
+            return self._variant_result(m, batch, kind, smoothing, want_grad, all_outputs, epoch,
+                                        batch_shared_entities is None or (not use_batch_shared_entities and not m.training))
         if m.training:
             m.dropout_step += 1
         batch.drop_cand = m.dropout_spec(H.STREAM_CAND)
@@ -138,6 +164,41 @@ class AddLossModule(nn.Module):
         else:
             loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, None, None, loss=kind, label_smoothing=smoothing,
                                         normalizer=1.0, scores=all_outputs, loss_only=True)
+            result = loss.to(torch.float32).reshape(())
+        return result, hook_loss, all_outputs
+
+    def _variant_result(self, m, batch, kind, smoothing, want_grad, all_outputs, epoch, all_entities):
+        """lookup embedder with batch_norm / projection / normalize / l2_reg on (model.py:463-479): torch encodes in the
+        reference's call order -- candidates once (trainer.py:75-82), then (rel, obj) of the po rows, (subj, rel) of the sp
+        rows (model.py:52-74) -- and the HIP scorer / loss / backward works on the encoded rows"""
+        dev = m.entity_embedding.weight.device
+        n_po, n_sp, n_c = batch.n_po, batch.n_sp, batch.n_candidates
+        with torch.set_grad_enabled(want_grad):
+            if all_entities:
+                cand = m.get_all_obj()
+            elif batch.cand_ids is not None:
+                cand = m.precompute_batch_shared_inputs(batch.cand_ids)
+            else:
+                cand = m.precompute_batch_shared_inputs(torch.arange(batch.cand_first, batch.cand_first + n_c, dtype=torch.int32, device=dev))
+            parts_e, parts_r = [cand.reshape(n_c, -1)], []
+            if n_po:
+                parts_r.append(m.encode_rel(batch.po_rel).reshape(n_po, -1))
+                parts_e.append(m.encode_obj(batch.po_obj).reshape(n_po, -1))
+            if n_sp:
+                parts_e.append(m.encode_subj(batch.sp_subj).reshape(n_sp, -1))
+                parts_r.append(m.encode_rel(batch.sp_rel).reshape(n_sp, -1))
+            EV, RV = torch.cat(parts_e), torch.cat(parts_r)
+        hook_loss = m.after_batch_loss_hook(epoch)
+        ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
+        vb = H.PrefixBatch(po_rel=ar(0, n_po) if n_po else None, po_obj=ar(n_c, n_c + n_po) if n_po else None,
+                           sp_subj=ar(n_c + n_po, n_c + n_po + n_sp) if n_sp else None, sp_rel=ar(n_po, n_po + n_sp) if n_sp else None,
+                           pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=n_c)
+        eng = m.engine()
+        if want_grad:
+            result = _VirtualTablesLossFn.apply(EV, RV, eng, m.scorer_name, vb, kind, smoothing, all_outputs)
+        else:
+            loss = eng.forward_backward(EV.detach().contiguous(), RV.detach().contiguous(), m.scorer_name, vb, None, None, loss=kind,
+                                        label_smoothing=smoothing, normalizer=1.0, scores=all_outputs, loss_only=True)
             result = loss.to(torch.float32).reshape(())
         return result, hook_loss, all_outputs
 

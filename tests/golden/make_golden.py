@@ -37,6 +37,8 @@ Vectors:
                   stored with torch.save (tensors / containers only), plus the third step's batch and result
   g7_traj_*       20 training steps, fixed batches -> loss curve and final tables, then compute_metrics on an
                   evaluation slice of the trained tables (scores, per-group ranks, MRR / MR / Hits)
+  g12_variant_*   LookupComplexRelationModel with batch_norm / project_entity / normalize='norm' / l2_reg on
+                  (model.py:463-479): loss, hook loss, outputs, every parameter's gradient, running stats, eval scores
   g11_traj_*      30 training steps at the BASELINE size on real FB15k-237 batches (reference dataset + collate), then
                   filtered ranks / MRR of the first valid.txt batch on the trained tables
 """
@@ -802,6 +804,60 @@ def g11():
 
 
 # ----------------------------------------------------------------------------------------------
+# G12: embedder variants of the lookup models (batch-norm, entity projection, normalisation, l2_reg hook)
+# ----------------------------------------------------------------------------------------------
+def g12():
+    """LookupComplexRelationModel with the _encode variants of model.py:463-479 switched on (dropout 0: torch's CPU
+    Bernoulli stream is not reproducible elsewhere): AddLossModule forward, Trainer's backward_loss = (loss + hook) /
+    normalizer (trainer.py:217-222), gradients of EVERY parameter, batch-norm running statistics after the step, and an
+    eval-mode forward afterwards."""
+    cases = {"bn": dict(batch_norm=True), "proj": dict(project_entity=True), "norm": dict(normalize="norm"),
+             "l2": dict(l2_reg=0.01), "all": dict(batch_norm=True, project_entity=True, normalize="norm", l2_reg=0.01)}
+    n_ent, n_rel, d, b = 60, 8, 16, 6
+    for name, kw in cases.items():
+        seed = 120 + len(name)
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(seed)
+        m = Models.LookupComplexRelationModel(entity_slot_size=d, input_dropout=0.0, init_std=0.3, sparse=False,
+                                              train_data=meta(n_ent, n_rel), **kw)
+        m.train()
+        state0 = {k: npy(v).copy() for k, v in m.state_dict().items()}
+        mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+        mod.train()
+        cand = torch.arange(n_ent)[2:].int().unsqueeze(1)
+        N = cand.shape[0]
+        po_rel, po_obj = rand_ids(rng, 2, n_rel, b), rand_ids(rng, 2, n_ent, b)
+        sp_subj, sp_rel = rand_ids(rng, 2, n_ent, b), rand_ids(rng, 2, n_rel, b)
+        y = dense_labels(rng, 2 * b, N)
+        loss, hook, outputs = mod(inputs=[(po_rel, po_obj), (sp_subj, sp_rel)], labels=torch.from_numpy(y.copy()),
+                                  use_batch_shared_entities=False, batch_shared_entities=cand, epoch=1,
+                                  input_style_triple_or_prefix="right_and_left_prefix")
+        normalizer = float(2 * b * N)
+        backward_loss = loss.sum()
+        if hook is not None:
+            backward_loss = backward_loss + hook
+        (backward_loss / normalizer).backward()
+        out = dict(case=np.str_(name), kw_keys=np.asarray(sorted(kw)), po_rel=npy(po_rel), po_obj=npy(po_obj), sp_subj=npy(sp_subj),
+                   sp_rel=npy(sp_rel), cand=npy(cand), labels=y, loss=np.float64(loss.item()),
+                   hook=np.float64(hook.item() if hook is not None else 0.0), has_hook=np.bool_(hook is not None),
+                   outputs=npy(outputs), normalizer=np.float64(normalizer),
+                   batch_norm=np.bool_(kw.get("batch_norm", False)), project_entity=np.bool_(kw.get("project_entity", False)),
+                   normalize=np.str_(kw.get("normalize", "")), l2_reg=np.float64(kw.get("l2_reg", 0)))
+        for k, v in state0.items():
+            out["p0_" + k] = v
+        for k, prm in m.named_parameters():
+            out["g_" + k] = npy(prm.grad) if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
+        for k, v in m.state_dict().items():
+            if "running" in k:
+                out["after_" + k] = npy(v)
+        m.eval()
+        with torch.no_grad():
+            ev = torch.cat([m.po_prefix_score(po_rel, po_obj), m.sp_prefix_score(sp_subj, sp_rel)], 0)
+        out["eval_outputs"] = npy(ev)
+        save("g12_variant_" + name, **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G8: checkpoint interop (Trainer.save layout, trainer.py:608-618)
 # ----------------------------------------------------------------------------------------------
 def g8():
@@ -847,7 +903,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -29,9 +29,10 @@ def test_registry_and_state_dict_keys():
     assert Models.LookupDistmultRelationModel.scorer_name == "distmult"
 
 
-@pytest.mark.parametrize("kw", [dict(batch_norm=True), dict(normalize="norm"), dict(l2_reg=0.1), dict(sparse=True),
-                                dict(project_entity=True)])
+@pytest.mark.parametrize("kw", [dict(sparse=True), dict(normalize="bogus"), dict(entity_embedding_size=5)])
 def test_unsupported_embedder_variants_raise(kw):
+    """sparse gradients / unknown normalisation / an embedding size without its projection; batch_norm, project_entity,
+    normalize='norm' and l2_reg fall through to torch (tests/test_embedder_variants.py)"""
     from open_knowledge_graph_embeddings_amd.dataset import EntityRelationDatasetMeta
     from open_knowledge_graph_embeddings_amd.model import Models
     meta = EntityRelationDatasetMeta(entities_size=10, relations_size=5)
