@@ -130,6 +130,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Geometry {
     int    B, N, d, Bpad, D16, KB, LDK, ldq, ldg, tiles, b_split, b_per_block, nsplit;
     int    tile_w, ktiles;      // fused train kernel: tile width (32 or 64 candidates) and tile count
+    bool   dq8;
     // training sweeps the candidates in RANGES of range_n (a multiple of 64) so that the one (B, N)-shaped
     // intermediate, G^T, and everything sized like it (masked rows Cm, KL statistics) is O(B x range_n):
     // 41 GB -> 1 GB at |E| = 2.5 M, B = 4096.  A range is one tile-kernel launch + one dq launch (slabs accumulate).
@@ -185,8 +186,9 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.b_per_block = (bblks + bs - 1) / bs * BC;
     g.b_split = (g.Bpad + g.b_per_block - 1) / g.b_per_block;
     if (g.n_ranges > 1) { g.b_split = 1; g.b_per_block = g.Bpad; }   // many tiles: no batch split
-    // dQ kernel: (batch block, candidate range) workgroups, two per CU (measured: 512 beats 256 workgroups)
-    int ns = std::max(1, 512 / bblks);
+    // dQ kernel: (batch block, candidate range) workgroups: 8-wave workgroups, one per CU (d <= 256), else 4-wave, two per CU
+    g.dq8 = g.KB <= 16 && env_int("OKGE_DQ8", 1) != 0;
+    int ns = std::max(1, (g.dq8 ? 256 : 512) / bblks);
     if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
     ns = env_int("OKGE_DQ_SPLIT", ns);
     ns = std::max(1, std::min(ns, g.range_tiles));
@@ -442,6 +444,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     q.slab = reinterpret_cast<float *>(ws + g.off_slab);
     q.d = g.d; q.KB = g.KB; q.LDK = g.LDK; q.Bpad = g.Bpad; q.ldq = g.ldq; q.ldg = g.ldg;
     q.nsplit = g.nsplit;
+    q.waves8 = g.dq8 ? 1 : 0;
     const int mode = loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE;
     for (int r = 0; r < g.n_ranges; ++r) {
         int tiles_r;

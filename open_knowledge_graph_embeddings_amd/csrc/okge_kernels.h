@@ -55,6 +55,7 @@ struct DqArgs {
     float         *slab;       // [nsplit][Bpad][ldq]
     int32_t        d, KB, LDK, N, Bpad, ldq, ldg, nsplit;
     int32_t        accumulate; // add to the slabs instead of overwriting them (candidate ranges after the first)
+    int32_t        waves8;     // dq8_kernel: one 8-wave workgroup per CU, contraction split over two wave groups (d <= 256)
 };
 
 struct PrefixDev {

@@ -96,9 +96,9 @@ __device__ __forceinline__ void load_cand_tile(float *Cs, uint8_t *keepb, float 
 //   brow : &B[16*s][0] + lane column offset handled here
 // Contraction row of (slot s, step t) is 16*s + t.  A is read 4 steps at a time when A_VEC (A stored with
 // the contraction index contiguous), else one ds_read_b32 per step.
-template <int KB, bool A_VEC, int LDK = lds_ld(16 * KB)>      // LDK: leading dimension of the B tile (wider than 16*KB when
-__device__ __forceinline__ void grad_product(v4f (&acc)[KB], const float *a_base, int lda, const float *b_base,   // a wave
-                                             int c)                                                                // takes a column range of it)
+template <int KB, bool A_VEC, int LDK = lds_ld(16 * KB), int T0 = 0, int T1 = 16>   // LDK: leading dimension of the B tile (wider
+__device__ __forceinline__ void grad_product(v4f (&acc)[KB], const float *a_base, int lda, const float *b_base,   // than 16*KB when a
+                                             int c)                            // wave takes a column range of it); steps T0 .. T1-1
 {
     constexpr int KQ = KB / 4, KR = KB % 4;
     // b_base points at B[16*s][0].  Operands of step t+1 are requested before the KB MFMAs of step t issue.
@@ -107,14 +107,14 @@ __device__ __forceinline__ void grad_product(v4f (&acc)[KB], const float *a_base
     float pa, na = 0.f;
     auto a_at = [&](int t) { return A_VEC ? a_base[t] : a_base[t * lda]; };   // A[out][16s + t]  |  A[16s + t][out]
 #pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) pb[kq] = *reinterpret_cast<const v4f *>(b_base + 64 * kq + 4 * c);
+    for (int kq = 0; kq < KQ; ++kq) pb[kq] = *reinterpret_cast<const v4f *>(b_base + T0 * LDK + 64 * kq + 4 * c);
 #pragma unroll
-    for (int r = 0; r < KR; ++r) pr[r] = b_base[64 * KQ + 16 * r + c];
-    pa = a_at(0);
+    for (int r = 0; r < KR; ++r) pr[r] = b_base[T0 * LDK + 64 * KQ + 16 * r + c];
+    pa = a_at(T0);
     __builtin_amdgcn_sched_group_barrier(0x100, KQ + KR + 1, 2);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        if (t + 1 < 16) {
+    for (int t = T0; t < T1; ++t) {
+        if (t + 1 < T1) {
             const float *brow = b_base + (t + 1) * LDK;
 #pragma unroll
             for (int kq = 0; kq < KQ; ++kq) nb[kq] = *reinterpret_cast<const v4f *>(brow + 64 * kq + 4 * c);
@@ -131,7 +131,7 @@ __device__ __forceinline__ void grad_product(v4f (&acc)[KB], const float *a_base
         }
 #pragma unroll
         for (int r = 0; r < KR; ++r) acc[4 * KQ + r] = mfma16(pa, pr[r], acc[4 * KQ + r]);
-        if (t + 1 < 16) {
+        if (t + 1 < T1) {
 #pragma unroll
             for (int kq = 0; kq < KQ; ++kq) pb[kq] = nb[kq];
 #pragma unroll
@@ -473,6 +473,115 @@ __global__ __launch_bounds__(DqCfg<KB>::THREADS) void dq_kernel(const DqArgs a)
     }
 }
 
+// ---- dQ = G . C, eight waves: the contraction of a 64-candidate chunk split over two wave groups ---------------------
+// Slot sizes up to 256.  Same workgroup-level job as dq_kernel (64 batch rows x a candidate range -> one slab), but one
+// 8-wave workgroup per CU takes a range TWICE as long: half the slabs (13.6 instead of 27 MB written here and read back
+// by the prefix backward at S-FB), half the first-chunk burst at kernel start, prologue / epilogue amortised over twice
+// the chunks -- at two waves per SIMD like the two co-resident 4-wave workgroups before.  Wave (wq = w & 3, kh = w >> 2):
+// batch rows 16wq.., contraction steps 8kh .. 8kh+7 of every slot (candidates 16s + 8kh + t: slots stay 16 rows apart, the
+// B operand reads keep their conflict-free bank pattern); the two halves are added through LDS before the slab store.
+template <int KB>
+__global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LDK = lds_ld(16 * KB);
+    constexpr int NTHR = 512, QG = 16;                // staging: 16 column groups per row, 32 rows per pass
+    constexpr int KQ = KB / 4, KR = KB % 4;
+    constexpr int NO = 2 * KB, NOIT = (NO + QG - 1) / QG;
+    float *Cs = reinterpret_cast<float *>(smem);      // [NT][LDK]   masked candidate rows (end: the kh = 1 partial sums)
+    float *Gt = Cs + NT * LDK;                        // [NT (n)][LDGT] : G^T tile, 64 batch rows wide
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, s = lane >> 4;
+    const int wq = w & 3, kh = w >> 2;
+    const int split = blockIdx.x % a.nsplit, bblk = blockIdx.x / a.nsplit;
+    const int b0 = bblk * BC;
+    const int nJ = a.Bpad / BC;
+    const int nchunks = (a.N + NT - 1) / NT;
+    const int ch_lo = (int)((int64_t)split * nchunks / a.nsplit);
+    const int ch_hi = (int)((int64_t)(split + 1) * nchunks / a.nsplit);
+
+    v4f acc[KB];                                      // dQ[b = b0 + 16wq + 4s + i][k = grad_col(kbi, c)], this wave's candidates
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) acc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    // register-staged prefetch of the next chunk: 2 float4 of the G^T block, 2 x NOIT x 2 float4 of the candidate tile
+    v4f gv[2], cv[4 * NOIT];
+    auto prefetch = [&](int ch) {
+        const float *g_blk = a.G + ((size_t)ch * nJ + bblk) * 4096;
+        const float *cm = a.Cm + (size_t)ch * NT * (16 * KB);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) gv[it] = *reinterpret_cast<const v4f *>(g_blk + (size_t)(tid + it * NTHR) * 4);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = tid / QG + 32 * pass;
+#pragma unroll
+            for (int it = 0; it < NOIT; ++it) {
+                const int o = min(tid % QG + QG * it, NO - 1);   // clamped: surplus lanes reload the last octet
+                cv[(2 * pass) * NOIT + it] = *reinterpret_cast<const v4f *>(cm + (size_t)r * (16 * KB) + 8 * o);
+                cv[(2 * pass + 1) * NOIT + it] = *reinterpret_cast<const v4f *>(cm + (size_t)r * (16 * KB) + 8 * o + 4);
+            }
+        }
+    };
+    if (ch_lo < ch_hi) prefetch(ch_lo);
+    for (int ch = ch_lo; ch < ch_hi; ++ch) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int f = tid + it * NTHR;
+            *reinterpret_cast<v4f *>(Gt + (f >> 4) * LDGT + 4 * (f & 15)) = gv[it];
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = tid / QG + 32 * pass;
+#pragma unroll
+            for (int it = 0; it < NOIT; ++it) {
+                const int o = tid % QG + QG * it;
+                if (o < NO) {
+                    *reinterpret_cast<v4f *>(Cs + r * LDK + 8 * o) = cv[(2 * pass) * NOIT + it];
+                    *reinterpret_cast<v4f *>(Cs + r * LDK + 8 * o + 4) = cv[(2 * pass + 1) * NOIT + it];
+                }
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < ch_hi) prefetch(ch + 1);
+        // A[i = b][slot s, step t] = G^T[n = 16s + t][b = 16wq + c] ; B[slot][k] = C[n = 16s + t][k]
+        if (kh == 0) grad_product<KB, false, LDK, 0, 8>(acc, Gt + 16 * s * LDGT + 16 * wq + c, LDGT, Cs + 16 * s * LDK, c);
+        else         grad_product<KB, false, LDK, 8, 16>(acc, Gt + 16 * s * LDGT + 16 * wq + c, LDGT, Cs + 16 * s * LDK, c);
+        __syncthreads();
+    }
+    // the two contraction halves: kh = 1 parks its partial rows in LDS, kh = 0 adds them and stores the slab rows
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *dst = Cs + (16 * wq + 4 * s + i) * LDK;
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq)
+                *reinterpret_cast<v4f *>(dst + 64 * kq + 4 * c) = (v4f){acc[4 * kq][i], acc[4 * kq + 1][i], acc[4 * kq + 2][i], acc[4 * kq + 3][i]};
+#pragma unroll
+            for (int r = 0; r < KR; ++r) dst[64 * KQ + 16 * r + c] = acc[4 * KQ + r][i];
+        }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *src = Cs + (16 * wq + 4 * s + i) * LDK;
+            float *dst = a.slab + ((size_t)split * a.Bpad + b0 + 16 * wq + 4 * s + i) * a.ldq;
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                v4f v = (v4f){acc[4 * kq][i], acc[4 * kq + 1][i], acc[4 * kq + 2][i], acc[4 * kq + 3][i]} +
+                        *reinterpret_cast<const v4f *>(src + 64 * kq + 4 * c);
+                if (a.accumulate) v += *reinterpret_cast<const v4f *>(dst + 64 * kq + 4 * c);
+                *reinterpret_cast<v4f *>(dst + 64 * kq + 4 * c) = v;
+            }
+#pragma unroll
+            for (int r = 0; r < KR; ++r) {
+                const float v = acc[4 * KQ + r][i] + src[64 * KQ + 16 * r + c];
+                dst[64 * KQ + 16 * r + c] = a.accumulate ? dst[64 * KQ + 16 * r + c] + v : v;
+            }
+        }
+    }
+}
+
 // ---- host-side launchers -----------------------------------------------------------------------------
 template <int KB, int MODE>
 static hipError_t launch_fused_t(const FusedArgs &a, dim3 grid, size_t shmem, hipStream_t st)
@@ -538,9 +647,32 @@ static hipError_t launch_dq_t(const DqArgs &a, int grid_x, size_t shmem, hipStre
     return hipGetLastError();
 }
 
+template <int KB>
+static hipError_t launch_dq8_t(const DqArgs &a, int grid_x, size_t shmem, hipStream_t st)
+{
+    auto k = dq8_kernel<KB>;
+    static size_t configured = 0;
+    if (shmem > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        configured = shmem;
+    }
+    hipLaunchKernelGGL(k, dim3(grid_x), dim3(512), shmem, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st)
 {
     const size_t shmem = dq_shmem_bytes(a.LDK);
+    if (a.waves8) {
+        switch (a.KB) {
+            case 4:  return launch_dq8_t<4>(a, grid_x, shmem, st);
+            case 8:  return launch_dq8_t<8>(a, grid_x, shmem, st);
+            case 13: return launch_dq8_t<13>(a, grid_x, shmem, st);
+            case 16: return launch_dq8_t<16>(a, grid_x, shmem, st);
+            default: break;
+        }
+    }
     switch (a.KB) {
         case 4:  return launch_dq_t<4>(a, grid_x, shmem, st);
         case 8:  return launch_dq_t<8>(a, grid_x, shmem, st);
