@@ -13,7 +13,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             name = row["Kernel_Name"].split("(")[0].replace("void okge::", "").replace("okge::", "")
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
-    if not any(x in k for x in ("fused", "dq_kernel", "prefix", "adagrad", "encode")):
+    if not any(x in k for x in ("fused", "dq", "prefix", "adagrad", "encode", "eval_")):
         continue
     print(k)
     for c in sorted(acc[k]):
