@@ -312,7 +312,7 @@ def main():
         # pipelined: the materialising path (scores on one stream, ranks + meters on another), kept for d > 256 / dropout
         for name, cls in (("fused", FusedEvaluator), ("pipelined", PipelinedEvaluator)):
             ev_run = cls(Et, Rt, w.scorer, engine=step.engine)
-            ev_run.run([cb] * 4)
+            ev_run.run([cb] * 64)       # a fresh side stream's first ~50 launches are slow (runtime-side pools): warm them
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res, n_groups = ev_run.run([cb] * n_it)

@@ -876,7 +876,7 @@ int okge_evaluate_batch(const okge_tables *t, const okge_prefix_batch *batch, co
 
 // ---- fused evaluation: no (B, N) score block ------------------------------------------------------------------------
 namespace {
-struct EvalGeometry { size_t off_Q, off_true, off_filt, off_counts, total; bool slab; };
+struct EvalGeometry { size_t off_Q, off_true, off_filt, off_rps, off_gshift, off_counts, total; bool slab; };
 constexpr size_t EVAL_SLAB_MAX = (size_t)256 << 20;      // per-tile count slabs up to 256 MB; beyond that: atomics
 bool eval_geometry(int B, int N, int d, int64_t n_groups, int64_t n_filter, Geometry &g, EvalGeometry &e)
 {
@@ -885,6 +885,8 @@ bool eval_geometry(int B, int N, int d, int64_t n_groups, int64_t n_filter, Geom
     e.off_Q = off;      off += align_up((size_t)g.Bpad * g.ldq * sizeof(float), 256);
     e.off_true = off;   off += align_up((size_t)std::max<int64_t>(n_groups, 1) * sizeof(float), 256);
     e.off_filt = off;   off += align_up((size_t)std::max<int64_t>(n_filter, 1) * sizeof(float), 256);
+    e.off_rps = off;    off += align_up((size_t)(g.Bpad + 1) * sizeof(int64_t), 256);       // row_ptr of the batch sorted by group count
+    e.off_gshift = off; off += align_up((size_t)g.Bpad * sizeof(int64_t), 256);             // original -> sorted group index, per row
     const size_t slab_bytes = (size_t)g.tiles * std::max<int64_t>(n_groups, 1) * sizeof(uint32_t);
     e.slab = slab_bytes <= EVAL_SLAB_MAX;
     e.off_counts = off; off += align_up(e.slab ? slab_bytes : (size_t)std::max<int64_t>(n_groups, 1) * 2 * sizeof(int32_t), 256);
@@ -926,6 +928,7 @@ static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_pref
     float *Q = reinterpret_cast<float *>(ws + eg.off_Q), *tru = reinterpret_cast<float *>(ws + eg.off_true);
     float *fx = reinterpret_cast<float *>(ws + eg.off_filt);
     int32_t *counts = reinterpret_cast<int32_t *>(ws + eg.off_counts);
+    int64_t *rps = reinterpret_cast<int64_t *>(ws + eg.off_rps), *gshift = reinterpret_cast<int64_t *>(ws + eg.off_gshift);
     hipError_t e = hipSuccess;
     if (phases & 1) {
         if (!eg.slab) {
@@ -935,13 +938,13 @@ static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_pref
         const PrefixDev p = to_dev(*batch, t);
         ScopedTimer tm("eval_points", st);
         e = launch_eval_points(t->E, t->R, t->d, t->scorer, p, Q, g.ldq, g.Bpad, g.KB, cand->ids, cand->first_id, cand->n, t->n_ent, row_ptr,
-                               grp_ptr, ids, filt_ptr, filt_col, tru, fx, st);
+                               grp_ptr, ids, filt_ptr, filt_col, tru, fx, rps, gshift, st);
         if (e != hipSuccess) return fail_hip(e, "eval_points");
     }
     FusedArgs a;
     fill_fused_common(a, g, t, cand, ws);
     a.Q = Q;
-    a.rk_row_ptr = row_ptr; a.rk_true = tru; a.rk_ngroups = n_groups;
+    a.rk_row_ptr = rps; a.rk_true = tru; a.rk_ngroups = n_groups;          // the sweep works on the sorted batch
     a.rk_counts = eg.slab ? nullptr : counts;
     a.rk_slab = eg.slab ? reinterpret_cast<uint32_t *>(counts) : nullptr;
     a.b_per_block = g.Bpad;
@@ -952,7 +955,7 @@ static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_pref
     }
     if (phases & 4) {
         ScopedTimer tm("eval_ranks", st);
-        e = launch_eval_ranks(a.rk_counts, a.rk_slab, g.tiles, tru, fx, filt_ptr, row_ptr, B, n_groups, ranks, acc, st);
+        e = launch_eval_ranks(a.rk_counts, a.rk_slab, g.tiles, tru, fx, filt_ptr, row_ptr, gshift, B, n_groups, ranks, acc, st);
         if (e != hipSuccess) return fail_hip(e, "eval_ranks");
     }
     return OKGE_OK;

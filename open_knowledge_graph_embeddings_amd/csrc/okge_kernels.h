@@ -127,9 +127,10 @@ hipError_t launch_rank_metrics(const int64_t *ranks, int64_t n, double *acc, hip
 hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
                               int KB, const int32_t *cand_ids, int cand_first, int n_cand, int64_t table_rows, const int64_t *row_ptr,
                               const int64_t *grp_ptr, const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col,
-                              float *true_out, float *filt_x, hipStream_t st);
+                              float *true_out, float *filt_x, int64_t *row_ptr_sorted, int64_t *gshift, hipStream_t st);
 hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int tiles, const float *true_scores, const float *filt_x, const int64_t *filt_ptr,
-                             const int64_t *row_ptr, int B, int64_t n_groups, int64_t *ranks, double *acc, hipStream_t st);
+                             const int64_t *row_ptr, const int64_t *gshift, int B, int64_t n_groups, int64_t *ranks, double *acc,
+                             hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, int col0, const float *true_in, float *true_out, int64_t *counts_out,

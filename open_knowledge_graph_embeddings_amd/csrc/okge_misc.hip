@@ -817,6 +817,12 @@ __device__ __forceinline__ float point_score(const float *__restrict__ q /* LDS,
 // One workgroup per batch row: the folded query row (-> Q for the tile sweep, and LDS), then the POINT scores the rank
 // rule needs besides the sweep's counts: each answer group's true score = max over its ids (dataset.py:436), and the
 // score under every filter entry (they are replaced by -1e8, dataset.py:441: corrected in eval_ranks_kernel).
+//
+// The sweep sees the batch SORTED BY GROUP COUNT (descending, stable): its counting loop runs as long as the busiest of a
+// wave's 16 rows, so rows with many answers are put together (measured: 2.4x fewer loop iterations at a mean of 1.8
+// groups per row).  Every workgroup finds its own row's position by counting the rows in front of it -- O(B) loads,
+// no sort kernel, no extra launch: pos = #{ng' > ng} + #{b' < b, ng' == ng}; the sorted CSR offset is the same sum over
+// ng'.  Q row, true scores and the sorted row_ptr go to the sorted positions; gshift[b] maps a group index back.
 __global__ __launch_bounds__(256) void eval_points_kernel(const float *__restrict__ E, const float *__restrict__ R, int d,
                                                           int scorer, const PrefixDev p, float *__restrict__ Q, int ldq,
                                                           int KB, const int32_t *__restrict__ cand_ids, int cand_first,
@@ -826,13 +832,42 @@ __global__ __launch_bounds__(256) void eval_points_kernel(const float *__restric
                                                           const int32_t *__restrict__ ids,
                                                           const int64_t *__restrict__ filt_ptr,
                                                           const int32_t *__restrict__ filt_col,
-                                                          float *__restrict__ true_out, float *__restrict__ filt_x)
+                                                          float *__restrict__ true_out, float *__restrict__ filt_x,
+                                                          int64_t *__restrict__ row_ptr_sorted, int64_t *__restrict__ gshift)
 {
     __shared__ float qs[512];
+    __shared__ int red_pos[4];
+    __shared__ long long red_start[4];
     const int b = blockIdx.x, B = p.n_po + p.n_sp;
+    // position of this row in the order sorted by group count, and the first sorted group index of the row
+    int pos = b;
+    int64_t start = 0, g_lo = 0, g_hi = 0;
+    if (b < B) {
+        g_lo = row_ptr[b]; g_hi = row_ptr[b + 1];
+        const int64_t ng = g_hi - g_lo;
+        int cnt = 0;
+        long long sum = 0;
+        for (int o = threadIdx.x; o < B; o += blockDim.x) {
+            const int64_t ngo = row_ptr[o + 1] - row_ptr[o];
+            const bool before = ngo > ng || (ngo == ng && o < b);
+            cnt += before;
+            sum += before ? ngo : 0;
+        }
+        cnt = wave_sum(cnt);
+        sum = (long long)wave_sum((double)sum);              // exact: group counts are far below 2^53
+        if ((threadIdx.x & 63) == 0) { red_pos[threadIdx.x >> 6] = cnt; red_start[threadIdx.x >> 6] = sum; }
+        __syncthreads();
+        pos = red_pos[0] + red_pos[1] + red_pos[2] + red_pos[3];
+        start = red_start[0] + red_start[1] + red_start[2] + red_start[3];
+        if (threadIdx.x == 0) {
+            row_ptr_sorted[pos] = start;
+            if (pos == B - 1) row_ptr_sorted[B] = start + ng;
+            gshift[b] = start - g_lo;
+        }
+    }
     encode_query_row(E, R, d, scorer, p, b, qs, nullptr, 16 * KB);
     __syncthreads();            // the row was written column-strided by other threads
-    for (int k = threadIdx.x; k < ldq; k += blockDim.x) Q[(size_t)b * ldq + k] = k < 16 * KB ? qs[k] : 0.f;
+    for (int k = threadIdx.x; k < ldq; k += blockDim.x) Q[(size_t)pos * ldq + k] = k < 16 * KB ? qs[k] : 0.f;
     if (b >= B) return;
     const bool vec_ok = (d & 3) == 0;
     auto cand_row = [&](int col) {            // col: a position in the candidate list (checked), then an entity row (checked)
@@ -840,11 +875,10 @@ __global__ __launch_bounds__(256) void eval_points_kernel(const float *__restric
         const int64_t cid = checked_row(cand_ids ? (int64_t)cand_ids[col] : (int64_t)cand_first + col, table_rows, p.id_err);
         return E + cid * d;
     };
-    const int64_t g_lo = row_ptr[b], g_hi = row_ptr[b + 1];
     for (int64_t g = g_lo + threadIdx.x; g < g_hi; g += blockDim.x) {
         float t = -INFINITY;
         for (int64_t j = grp_ptr[g]; j < grp_ptr[g + 1]; ++j) t = fmaxf(t, point_score(qs, cand_row(ids[j]), d, KB, vec_ok));
-        true_out[g] = t;
+        true_out[g + (start - g_lo)] = t;                    // sorted group index
     }
     const int64_t f_lo = filt_ptr[b], f_hi = filt_ptr[b + 1];
     for (int64_t f = f_lo + threadIdx.x; f < f_hi; f += blockDim.x) filt_x[f] = point_score(qs, cand_row(filt_col[f]), d, KB, vec_ok);
@@ -856,8 +890,9 @@ __global__ __launch_bounds__(256) void eval_points_kernel(const float *__restric
 __global__ __launch_bounds__(256) void eval_ranks_kernel(const int32_t *__restrict__ counts, const uint32_t *__restrict__ slab,
                                                          int tiles, const float *__restrict__ true_scores,
                                                          const float *__restrict__ filt_x, const int64_t *__restrict__ filt_ptr,
-                                                         const int64_t *__restrict__ row_ptr, int B, int64_t n_groups,
-                                                         int64_t *__restrict__ ranks, double *__restrict__ acc)
+                                                         const int64_t *__restrict__ row_ptr, const int64_t *__restrict__ gshift,
+                                                         int B, int64_t n_groups, int64_t *__restrict__ ranks,
+                                                         double *__restrict__ acc)
 {
     __shared__ double red[4][7];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -869,7 +904,8 @@ __global__ __launch_bounds__(256) void eval_ranks_kernel(const int32_t *__restri
             const int mid = (lo + hi) >> 1;
             if (row_ptr[mid] <= g) lo = mid; else hi = mid;
         }
-        const float t = true_scores[g];
+        const int64_t gs = g + gshift[lo];               // the group's index in the sweep's (sorted) numbering
+        const float t = true_scores[gs];
         int gt = 0, eq = 0;
         for (int64_t f = filt_ptr[lo] + lane; f < filt_ptr[lo + 1]; f += 64) {
             const float x = filt_x[f];
@@ -878,14 +914,14 @@ __global__ __launch_bounds__(256) void eval_ranks_kernel(const int32_t *__restri
         }
         if (slab)                                        // the sweep's per-tile packed counts of this group
             for (int tl = lane; tl < tiles; tl += 64) {
-                const uint32_t pk = slab[(size_t)tl * n_groups + g];
+                const uint32_t pk = slab[(size_t)tl * n_groups + gs];
                 gt += (int)(pk & 0xFFFFu);
                 eq += (int)(pk >> 16);
             }
         gt = wave_sum(gt);
         eq = wave_sum(eq);
         if (lane == 0) {
-            const int64_t r = (int64_t)(slab ? 0 : counts[2 * g]) + gt + ((int64_t)(slab ? 0 : counts[2 * g + 1]) + eq) / 2;
+            const int64_t r = (int64_t)(slab ? 0 : counts[2 * gs]) + gt + ((int64_t)(slab ? 0 : counts[2 * gs + 1]) + eq) / 2;
             ranks[g] = r;
             v[0] = 1.0;
             v[1] = (double)(1.0f / (float)(r + 1));       // fp32 reciprocal like the reference's (1/(rank+1).float())
@@ -1057,21 +1093,21 @@ namespace okge {
 hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
                               int KB, const int32_t *cand_ids, int cand_first, int n_cand, int64_t table_rows, const int64_t *row_ptr,
                               const int64_t *grp_ptr, const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col,
-                              float *true_out, float *filt_x, hipStream_t st)
+                              float *true_out, float *filt_x, int64_t *row_ptr_sorted, int64_t *gshift, hipStream_t st)
 {
     if (Bpad <= 0) return hipSuccess;
     hipLaunchKernelGGL(eval_points_kernel, dim3(Bpad), dim3(256), 0, st, E, R, d, scorer, p, Q, ldq, KB, cand_ids, cand_first,
-                       n_cand, table_rows, row_ptr, grp_ptr, ids, filt_ptr, filt_col, true_out, filt_x);
+                       n_cand, table_rows, row_ptr, grp_ptr, ids, filt_ptr, filt_col, true_out, filt_x, row_ptr_sorted, gshift);
     return hipGetLastError();
 }
 
 hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int tiles, const float *true_scores, const float *filt_x,
-                             const int64_t *filt_ptr, const int64_t *row_ptr, int B, int64_t n_groups, int64_t *ranks, double *acc,
-                             hipStream_t st)
+                             const int64_t *filt_ptr, const int64_t *row_ptr, const int64_t *gshift, int B, int64_t n_groups,
+                             int64_t *ranks, double *acc, hipStream_t st)
 {
     if (n_groups <= 0) return hipSuccess;
     hipLaunchKernelGGL(eval_ranks_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, st, counts, slab, tiles, true_scores, filt_x,
-                       filt_ptr, row_ptr, B, n_groups, ranks, acc);
+                       filt_ptr, row_ptr, gshift, B, n_groups, ranks, acc);
     return hipGetLastError();
 }
 

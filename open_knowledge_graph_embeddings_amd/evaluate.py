@@ -39,6 +39,9 @@ class FusedEvaluator:
         self._ws = [None, None]
         self._ranks = [None, None]
         self._t = self.engine._tables(E, R, scorer)
+        # two events per slot, created once (a fresh hipEvent per batch cost ~1 ms each until torch's pool had filled)
+        self._ev_pts = [torch.cuda.Event(), torch.cuda.Event()]
+        self._ev_swept = [torch.cuda.Event(), torch.cuda.Event()]
 
     def _args(self, cb, slot, acc):
         eng, b = self.engine, cb.batch
@@ -53,9 +56,8 @@ class FusedEvaluator:
             self.side.synchronize()
             self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
             self._ranks[slot].record_stream(self.side)
-        for x in (cb.filt_ptr, cb.filt_col, cb.row_ptr, cb.grp_ptr, cb.ids, b.po_rel, b.po_obj, b.sp_subj, b.sp_rel, b.cand_ids):
-            if x is not None:
-                x.record_stream(self.side)
+        # (the batch's tensors are read on the side stream too: run() keeps every batch referenced until both streams
+        #  have drained instead of paying ten record_stream calls per batch)
         return (ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c), cb.filt_ptr.data_ptr(),
                 cb.filt_col.data_ptr() if n_filter else None, n_filter, cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(),
                 cb.ids.data_ptr(), n_groups, self._ranks[slot].data_ptr(), acc.data_ptr(), self._ws[slot].data_ptr(),
@@ -74,30 +76,28 @@ class FusedEvaluator:
         if cur is None:
             return _meters(acc.cpu().tolist())
         cur_args, ka = self._args(cur, 0, acc)
-        keep_alive.append(ka)
+        keep_alive.append((ka, cur))
         N.check(lib.okge_evaluate_fused_phase(1, *cur_args, side_h), "okge_evaluate_fused_phase(points)")
-        pts = torch.cuda.Event()
+        pts = self._ev_pts[0]
         pts.record(self.side)
         while cur is not None:
             main.wait_event(pts)
             N.check(lib.okge_evaluate_fused_phase(2, *cur_args, main_h), "okge_evaluate_fused_phase(sweep)")
-            swept = torch.cuda.Event()
+            swept = self._ev_swept[i & 1]
             swept.record(main)
             nxt = next(it, None)
             if nxt is not None:                              # next batch's point scores go in BEFORE this batch's ranks
                 nxt_args, ka = self._args(nxt, (i + 1) & 1, acc)
-                keep_alive.append(ka)
+                keep_alive.append((ka, nxt))
                 N.check(lib.okge_evaluate_fused_phase(1, *nxt_args, side_h), "okge_evaluate_fused_phase(points)")
-                pts = torch.cuda.Event()
+                pts = self._ev_pts[(i + 1) & 1]
                 pts.record(self.side)
             self.side.wait_event(swept)
             N.check(lib.okge_evaluate_fused_phase(4, *cur_args, side_h), "okge_evaluate_fused_phase(ranks)")
             cur, cur_args = nxt, (nxt_args if nxt is not None else None)
             i += 1
-            if len(keep_alive) > 4:
-                keep_alive.pop(0)
         main.wait_stream(self.side)
-        out = _meters(acc.cpu().tolist())
+        out = _meters(acc.cpu().tolist())          # (synchronises: every kernel that read a batch has finished)
         del keep_alive
         return out
 
