@@ -178,9 +178,16 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.tile_w = env_int("OKGE_TILE_W", g.tile_w) == 32 ? 32 : g.tile_w;      // diagnostic: the round-1 cut
     g.ktiles = g.tiles * (NT / g.tile_w);
     const int slots = g.tile_w == 64 ? 256 : 512;
-    // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y
+    // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y.  The split that minimises
+    // (rounds of workgroups over the slots) x (row blocks per workgroup); ties go to the coarser split (fewer slabs).
     int bs = 1;
-    if (g.ktiles < slots * 3 / 4) bs = std::min(bblks, (slots + g.ktiles - 1) / g.ktiles);
+    if (g.ktiles < slots * 3 / 4) {
+        long best = -1;
+        for (int c = 1; c <= bblks; ++c) {
+            const long rounds = ((long)g.ktiles * c + slots - 1) / slots, per = (bblks + c - 1) / c;
+            if (best < 0 || rounds * per < best) { best = rounds * per; bs = c; }
+        }
+    }
     bs = std::max(1, env_int("OKGE_B_SPLIT", bs));
     bs = std::min(bs, bblks);
     g.b_per_block = (bblks + bs - 1) / bs * BC;
