@@ -24,13 +24,24 @@ struct DropDev {
 __device__ __forceinline__ uint32_t drop_step(const DropDev &dr) { return dr.step_dev ? *dr.step_dev : dr.step; }
 
 // ---- Philox4x32-10 (Salmon et al. 2011), Random123 known-answer vectors in tests/ -------------------
+// WIDE: one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi / v_mul_lo pair -- the integer
+// multiplies are quarter-rate and set the cost of a round; same numbers.  (The tile kernels use it; hipcc 7.2 fails to
+// select instructions for some of the small kernels of okge_misc.hip with it, so it is opt-in.)
+template <bool WIDE = false>
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                 uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t hi0, lo0, hi1, lo1;
+        if (WIDE) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+            hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+            hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        } else {
+            hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        }
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
@@ -42,7 +53,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
 // Keep flags (bit e = column 8*o8 + e) of eight consecutive columns of row `row_pos` of a gathered block with
 // `d` columns.  One Philox call yields 8 uniform 16-bit numbers: word e>>1, low half for even e, high half
 // for odd e; keep <=> u16 >= thr (thr = floor(p * 65536)).  Columns >= d report "drop".
-__device__ __forceinline__ uint32_t drop_keep8(const DropDev &dr, uint32_t row_pos, int o8, int d)
+// (`step` = drop_step(dr), fetched once by the caller: with a device-resident counter it is a load, and a load between a
+//  kernel's gather and its mask arithmetic makes the arithmetic wait for the gather -- vmcnt retires in order)
+template <bool WIDE = false>
+__device__ __forceinline__ uint32_t drop_keep8(const DropDev &dr, uint32_t row_pos, int o8, int d, uint32_t step)
 {
     uint32_t bits = 0;
     if (dr.keep) {
@@ -52,7 +66,7 @@ __device__ __forceinline__ uint32_t drop_keep8(const DropDev &dr, uint32_t row_p
             if (8 * o8 + e < d && kp[e]) bits |= 1u << e;
         return bits;
     }
-    const uint4 u = philox4x32_10(row_pos, (uint32_t)o8, dr.stream, drop_step(dr), dr.k0, dr.k1);
+    const uint4 u = philox4x32_10<WIDE>(row_pos, (uint32_t)o8, dr.stream, step, dr.k0, dr.k1);
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -60,6 +74,11 @@ __device__ __forceinline__ uint32_t drop_keep8(const DropDev &dr, uint32_t row_p
         if (u16 >= dr.thr && 8 * o8 + e < d) bits |= 1u << e;
     }
     return bits;
+}
+
+__device__ __forceinline__ uint32_t drop_keep8(const DropDev &dr, uint32_t row_pos, int o8, int d)
+{
+    return drop_keep8(dr, row_pos, o8, d, drop_step(dr));
 }
 
 __device__ __forceinline__ float drop_mult1(const DropDev &dr, uint32_t row_pos, int k, int d)

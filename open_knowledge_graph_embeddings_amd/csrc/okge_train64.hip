@@ -106,6 +106,7 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
             qreg[it] = (b < b_end) ? *reinterpret_cast<const v4f *>(src + 4 * q) : (v4f){0.f, 0.f, 0.f, 0.f};
         }
     };
+    const uint32_t dstep = a.drop_c.enabled ? drop_step(a.drop_c) : 0u;   // before the loads whose latency hides the masks
     fetch_chunk(b_begin);
 
     // positives of this tile: offsets requested before the gather (their loads overlap the candidate rows')
@@ -120,16 +121,23 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
         if (valid) cid = checked_row(a.cand_ids ? (int64_t)a.cand_ids[n] : (int64_t)a.cand_first + n, a.n_table_rows, q8 ? nullptr : a.id_err);
         const float *row = a.E + cid * d;
         v4f v0[NOIT], v1[NOIT];
+        if (vec_ok) {
+            // branch-free: every thread issues its 2*NOIT 16-byte loads back to back (out-of-range pieces read the row's
+            // first floats and are zeroed below), so the row's round trips to HBM overlap instead of queueing up
 #pragma unroll
-        for (int it = 0; it < NOIT; ++it) {
-            const int o = q8 + QG * it, k = 8 * o;
-            v0[it] = (v4f){0.f, 0.f, 0.f, 0.f};
-            v1[it] = (v4f){0.f, 0.f, 0.f, 0.f};
-            if (o < NO && valid && k < d) {
-                if (vec_ok) {
-                    v0[it] = *reinterpret_cast<const v4f *>(row + k);
-                    if (k + 4 < d) v1[it] = *reinterpret_cast<const v4f *>(row + k + 4);
-                } else {
+            for (int it = 0; it < NOIT; ++it) {
+                const int o = q8 + QG * it, k = 8 * o;
+                const bool in0 = o < NO && valid && k < d, in1 = in0 && k + 4 < d;
+                v0[it] = *reinterpret_cast<const v4f *>(row + (in0 ? k : 0));
+                v1[it] = *reinterpret_cast<const v4f *>(row + (in1 ? k + 4 : 0));
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NOIT; ++it) {
+                const int o = q8 + QG * it, k = 8 * o;
+                v0[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+                v1[it] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (o < NO && valid && k < d) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (k + e < d) v0[it][e] = row[k + e];
@@ -139,6 +147,16 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
             }
         }
         TL_STAMP_AT(40);   // gather loads issued
+        // the keep bits depend on (candidate, octet, seed) only: computed while the rows are in flight
+        uint32_t bits[NOIT];
+#pragma unroll
+        for (int it = 0; it < NOIT; ++it) {
+            const int o = q8 + QG * it, k = 8 * o;
+            bits[it] = (o < NO && valid && k < d) ? 0xFFu : 0u;
+            if (a.drop_c.enabled && bits[it]) bits[it] = drop_keep8<true>(a.drop_c, (uint32_t)(n + a.cand_col0), o, d, dstep);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (after the mask arithmetic: vmcnt retires in order, so waiting for these loads waits for the rows as well)
         for (int i = tid; i < pos_cached; i += T64_THREADS)
             posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - a.cand_col0 - n0);
         if (tid < 2 * BC64 * 2) ybits2[tid] = 0u;
@@ -146,18 +164,15 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
         for (int it = 0; it < NOIT; ++it) {
             const int o = q8 + QG * it, k = 8 * o;
             if (o < NO) {
-                uint32_t bits = 0xFFu;
-                if (a.drop_c.enabled) {
-                    bits = (valid && k < d) ? drop_keep8(a.drop_c, (uint32_t)(n + a.cand_col0), o, d) : 0u;
+                const float sc = a.drop_c.enabled ? a.drop_c.scale : 1.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v0[it][e] *= (bits >> e & 1u) ? a.drop_c.scale : 0.f;
-                        v1[it][e] *= (bits >> (4 + e) & 1u) ? a.drop_c.scale : 0.f;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    v0[it][e] = (bits[it] >> e & 1u) && k + e < d ? v0[it][e] * sc : 0.f;
+                    v1[it][e] = (bits[it] >> (4 + e) & 1u) && k + 4 + e < d ? v1[it][e] * sc : 0.f;
                 }
                 *reinterpret_cast<v4f *>(Cs + r8 * LDK + k) = v0[it];
                 *reinterpret_cast<v4f *>(Cs + r8 * LDK + k + 4) = v1[it];
-                keepb[r8 * KEEP_LD + o] = (uint8_t)bits;
+                keepb[r8 * KEEP_LD + o] = (uint8_t)bits[it];
             }
         }
     }
