@@ -259,15 +259,6 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const double *__restri
     loss_reduce_block(partials, n, out);
 }
 
-__device__ __forceinline__ float4 keep_mult4(const DropDev &dr, uint32_t pos, int k, int d)
-{
-    if (!dr.enabled) return make_float4(1.f, 1.f, 1.f, 1.f);
-    const uint32_t nib = (drop_keep8(dr, pos, k >> 3, d) >> (k & 4)) & 15u;
-    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-    apply_keep4(m, nib, dr.scale);
-    return m;
-}
-
 __device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c)
 {
@@ -329,16 +320,33 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
         }
         return acc;
     };
+    // The keep nibbles of a column group: lane sq computes ONE of the (up to four) Philox calls the group needs and the
+    // chain-rule lane collects them by shuffles; the table rows are requested before the slab sums so that their round
+    // trip overlaps the slabs' (ids -> {rows, slabs, masks} -> atomics instead of ids -> slabs -> masks -> rows -> atomics).
+    const int lane0 = (threadIdx.x & 63) & ~3;
+    auto nibble = [&](const DropDev &dd, int k, bool active) -> uint32_t {
+        if (!dd.enabled) return 15u;
+        return active ? (drop_keep8(dd, rs.pos, k >> 3, d) >> (k & 4)) & 15u : 0u;
+    };
+    auto mult4 = [&](const DropDev &dd, uint32_t nib) {
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (dd.enabled) apply_keep4(m, nib, dd.scale);
+        return m;
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (scorer == SC_DISTMULT) {
         for (int k0 = 0; k0 < d; k0 += 128) {
             const int k = k0 + 4 * grp;
-            const bool act = k < d;
+            const bool act = k < d, lead = act && sq == 0;
+            const float4 ev0 = lead ? *reinterpret_cast<const float4 *>(e + k) : zero4;
+            const float4 rv0 = lead ? *reinterpret_cast<const float4 *>(r + k) : zero4;
+            const uint32_t nib = nibble((sq & 1) ? dr : de, k, act && sq < 2);
+            const uint32_t nib_e = __shfl(nib, lane0), nib_r = __shfl(nib, lane0 + 1);
             const float4 dq = dq_sum(act ? k : 0, act);
-            if (act && sq == 0) {
-                const float4 me = keep_mult4(de, rs.pos, k, d), mr = keep_mult4(dr, rs.pos, k, d);
-                float4 ev = *reinterpret_cast<const float4 *>(e + k);
-                if (!e_masked) ev = f4mul(ev, me);
-                const float4 rv = f4mul(*reinterpret_cast<const float4 *>(r + k), mr);
+            if (lead) {
+                const float4 me = mult4(de, nib_e), mr = mult4(dr, nib_r);
+                const float4 ev = e_masked ? ev0 : f4mul(ev0, me);
+                const float4 rv = f4mul(rv0, mr);
                 if (rs.owned) atomic_add4(ge + k, f4mul(f4mul(dq, rv), me));
                 atomic_add4(gr + k, f4mul(f4mul(dq, ev), mr));
             }
@@ -348,15 +356,21 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
     const int h = d >> 1;
     for (int k0 = 0; k0 < h; k0 += 128) {
         const int k = k0 + 4 * grp;
-        const bool act = k < h;
+        const bool act = k < h, lead = act && sq == 0;
+        float4 e1 = zero4, e2 = zero4, r1 = zero4, r2 = zero4;
+        if (lead) {
+            e1 = *reinterpret_cast<const float4 *>(e + k);  e2 = *reinterpret_cast<const float4 *>(e + h + k);
+            r1 = *reinterpret_cast<const float4 *>(r + k);  r2 = *reinterpret_cast<const float4 *>(r + h + k);
+        }
+        const uint32_t nib = nibble((sq & 2) ? dr : de, (sq & 1) ? h + k : k, act);
+        const uint32_t n_e1 = __shfl(nib, lane0), n_e2 = __shfl(nib, lane0 + 1);
+        const uint32_t n_r1 = __shfl(nib, lane0 + 2), n_r2 = __shfl(nib, lane0 + 3);
         const float4 q1 = dq_sum(act ? k : 0, act), q2 = dq_sum(act ? h + k : 0, act);
-        if (!(act && sq == 0)) continue;
-        const float4 me1 = keep_mult4(de, rs.pos, k, d), me2 = keep_mult4(de, rs.pos, h + k, d);
-        const float4 mr1 = keep_mult4(dr, rs.pos, k, d), mr2 = keep_mult4(dr, rs.pos, h + k, d);
-        float4 e1 = *reinterpret_cast<const float4 *>(e + k), e2 = *reinterpret_cast<const float4 *>(e + h + k);
+        if (!lead) continue;
+        const float4 me1 = mult4(de, n_e1), me2 = mult4(de, n_e2), mr1 = mult4(dr, n_r1), mr2 = mult4(dr, n_r2);
         if (!e_masked) { e1 = f4mul(e1, me1); e2 = f4mul(e2, me2); }
-        const float4 r1 = f4mul(*reinterpret_cast<const float4 *>(r + k), mr1);
-        const float4 r2 = f4mul(*reinterpret_cast<const float4 *>(r + h + k), mr2);
+        r1 = f4mul(r1, mr1);
+        r2 = f4mul(r2, mr2);
         float4 de1, de2, dr1, dr2;
         if (rs.sp) {
             de1 = f4fma(q1, r1, f4mul(q2, r2));           de2 = f4fma(q2, r1, f4neg(f4mul(q1, r2)));
