@@ -29,7 +29,7 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_score_workspace_bytes", "okge_lse_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
-           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_phase", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
+           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_phase", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
            "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
            "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
@@ -53,6 +53,12 @@ class PrefixBatch(Structure):
 class Candidates(Structure):
     _fields_ = [("ids", c_void_p), ("first_id", c_int32), ("n", c_int32), ("drop", Dropout), ("table", c_void_p),
                 ("table_rows", c_int32), ("_pad", c_int32)]
+
+
+class EvalBatch(Structure):
+    _fields_ = [("batch", PrefixBatch), ("cand", Candidates), ("filt_ptr", c_void_p), ("filt_col", c_void_p),
+                ("n_filter", c_int64), ("row_ptr", c_void_p), ("grp_ptr", c_void_p), ("ids", c_void_p),
+                ("n_groups", c_int64), ("rank_offset", c_int64)]
 
 
 class Tables(Structure):
@@ -220,6 +226,9 @@ def lib():
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     L.okge_evaluate_fused_phase.restype = c_int32
     L.okge_evaluate_fused_phase.argtypes = [c_int32] + L.okge_evaluate_fused.argtypes
+    L.okge_evaluate_fused_batches.restype = c_int32
+    L.okge_evaluate_fused_batches.argtypes = [POINTER(Tables), POINTER(EvalBatch), c_int32, c_void_p, c_void_p, c_void_p,
+                                              c_size_t, c_void_p]
     L.okge_eval_workspace_bytes.restype = c_size_t
     L.okge_eval_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int64, c_int64]
     L.okge_pool_workspace_bytes.restype = c_size_t

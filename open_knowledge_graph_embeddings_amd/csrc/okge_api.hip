@@ -883,7 +883,7 @@ int okge_evaluate_batch(const okge_tables *t, const okge_prefix_batch *batch, co
 
 // ---- fused evaluation: no (B, N) score block ------------------------------------------------------------------------
 namespace {
-struct EvalGeometry { size_t off_Q, off_true, off_filt, off_rps, off_gshift, off_counts, total; bool slab; };
+struct EvalGeometry { size_t off_Q, off_true, off_filt, off_rps, off_gshift, off_grow, off_counts, total; bool slab; };
 constexpr size_t EVAL_SLAB_MAX = (size_t)256 << 20;      // per-tile count slabs up to 256 MB; beyond that: atomics
 bool eval_geometry(int B, int N, int d, int64_t n_groups, int64_t n_filter, Geometry &g, EvalGeometry &e)
 {
@@ -894,6 +894,7 @@ bool eval_geometry(int B, int N, int d, int64_t n_groups, int64_t n_filter, Geom
     e.off_filt = off;   off += align_up((size_t)std::max<int64_t>(n_filter, 1) * sizeof(float), 256);
     e.off_rps = off;    off += align_up((size_t)(g.Bpad + 1) * sizeof(int64_t), 256);       // row_ptr of the batch sorted by group count
     e.off_gshift = off; off += align_up((size_t)g.Bpad * sizeof(int64_t), 256);             // original -> sorted group index, per row
+    e.off_grow = off;   off += align_up((size_t)std::max<int64_t>(n_groups, 1) * sizeof(int32_t), 256);     // row of every group
     const size_t slab_bytes = (size_t)g.tiles * std::max<int64_t>(n_groups, 1) * sizeof(uint32_t);
     e.slab = slab_bytes <= EVAL_SLAB_MAX;
     e.off_counts = off; off += align_up(e.slab ? slab_bytes : (size_t)std::max<int64_t>(n_groups, 1) * 2 * sizeof(int32_t), 256);
@@ -910,12 +911,24 @@ size_t okge_eval_workspace_bytes(int32_t B, int32_t N, int32_t d, int64_t n_grou
 }
 
 // phases: 1 = point scores (+ queries), 2 = tile sweep, 4 = ranks + meters; okge_evaluate_fused runs all three on one
-// stream, okge_evaluate_fused_phase lets a caller put them on different streams (evaluate.FusedEvaluator: the two small
-// latency-bound kernels of neighbouring batches run beside the sweep)
-static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
-                               const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
-                               const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
-                               void *workspace, size_t workspace_bytes, void *stream)
+// stream, okge_evaluate_fused_phase one at a time, okge_evaluate_fused_batches pairs phase 4 of a batch with phase 1 of
+// the next in one launch.
+namespace {
+struct EvalCall {                      // one batch's launch arguments, built once and used by whichever phases run
+    Geometry g;
+    EvalGeometry eg;
+    EvalPointsArgs pts;
+    EvalRanksArgs rk;
+    FusedArgs sweep;
+    int32_t *counts;
+    int64_t n_groups;
+};
+}  // namespace
+
+static int eval_call(EvalCall &c, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                     const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
+                     const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
+                     void *workspace, size_t workspace_bytes)
 {
     if (int rc = check_common(t, batch, cand)) return rc;
     if (!filt_ptr || !row_ptr || !grp_ptr || !ids || !ranks || !acc || n_groups < 0 || n_filter < 0 || (n_filter > 0 && !filt_col))
@@ -924,48 +937,74 @@ static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_pref
     if (cand->table || cand->drop.p > 0.f || batch->drop_po_ent.p > 0.f || batch->drop_sp_ent.p > 0.f ||
         batch->drop_po_rel.p > 0.f || batch->drop_sp_rel.p > 0.f)
         return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation is the eval-mode path (no dropout, candidates from the entity table)");
+    c.n_groups = n_groups;
     if (n_groups == 0) return OKGE_OK;
     const int32_t B = batch->n_po + batch->n_sp;
-    Geometry g;
-    EvalGeometry eg;
+    Geometry &g = c.g;
+    EvalGeometry &eg = c.eg;
     eval_geometry(B, cand->n, t->d, n_groups, n_filter, g, eg);
     if (!workspace || workspace_bytes < eg.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
     float *Q = reinterpret_cast<float *>(ws + eg.off_Q), *tru = reinterpret_cast<float *>(ws + eg.off_true);
     float *fx = reinterpret_cast<float *>(ws + eg.off_filt);
-    int32_t *counts = reinterpret_cast<int32_t *>(ws + eg.off_counts);
+    c.counts = reinterpret_cast<int32_t *>(ws + eg.off_counts);
     int64_t *rps = reinterpret_cast<int64_t *>(ws + eg.off_rps), *gshift = reinterpret_cast<int64_t *>(ws + eg.off_gshift);
-    hipError_t e = hipSuccess;
-    if (phases & 1) {
-        if (!eg.slab) {
-            e = hipMemsetAsync(counts, 0, (size_t)n_groups * 2 * sizeof(int32_t), st);
-            if (e != hipSuccess) return fail_hip(e, "clear rank counters");
-        }
-        const PrefixDev p = to_dev(*batch, t);
-        ScopedTimer tm("eval_points", st);
-        e = launch_eval_points(t->E, t->R, t->d, t->scorer, p, Q, g.ldq, g.Bpad, g.KB, cand->ids, cand->first_id, cand->n, t->n_ent, row_ptr,
-                               grp_ptr, ids, filt_ptr, filt_col, tru, fx, rps, gshift, st);
-        if (e != hipSuccess) return fail_hip(e, "eval_points");
-    }
-    FusedArgs a;
+    int32_t *grow = reinterpret_cast<int32_t *>(ws + eg.off_grow);
+    EvalPointsArgs &p = c.pts;
+    p.E = t->E; p.R = t->R; p.p = to_dev(*batch, t); p.Q = Q; p.cand_ids = cand->ids;
+    p.row_ptr = row_ptr; p.grp_ptr = grp_ptr; p.filt_ptr = filt_ptr; p.ids = ids; p.filt_col = filt_col;
+    p.true_out = tru; p.filt_x = fx; p.row_ptr_sorted = rps; p.gshift = gshift; p.group_row = grow;
+    p.table_rows = t->n_ent; p.d = t->d; p.scorer = t->scorer; p.ldq = g.ldq; p.KB = g.KB; p.Bpad = g.Bpad;
+    p.cand_first = cand->first_id; p.n_cand = cand->n;
+    FusedArgs &a = c.sweep;
     fill_fused_common(a, g, t, cand, ws);
     a.Q = Q;
     a.rk_row_ptr = rps; a.rk_true = tru; a.rk_ngroups = n_groups;          // the sweep works on the sorted batch
-    a.rk_counts = eg.slab ? nullptr : counts;
-    a.rk_slab = eg.slab ? reinterpret_cast<uint32_t *>(counts) : nullptr;
+    a.rk_counts = eg.slab ? nullptr : c.counts;
+    a.rk_slab = eg.slab ? reinterpret_cast<uint32_t *>(c.counts) : nullptr;
     a.b_per_block = g.Bpad;
+    EvalRanksArgs &r = c.rk;
+    r.counts = a.rk_counts; r.slab = a.rk_slab; r.true_scores = tru; r.filt_x = fx; r.filt_ptr = filt_ptr; r.gshift = gshift;
+    r.group_row = grow; r.ranks = ranks; r.acc = acc; r.n_groups = n_groups; r.tiles = g.tiles; r.B = B;
+    return OKGE_OK;
+}
+
+static int eval_issue(int phases, const EvalCall &c, hipStream_t st)
+{
+    if (c.n_groups == 0) return OKGE_OK;
+    hipError_t e = hipSuccess;
+    if (phases & 1) {
+        if (!c.eg.slab) {
+            e = hipMemsetAsync(c.counts, 0, (size_t)c.n_groups * 2 * sizeof(int32_t), st);
+            if (e != hipSuccess) return fail_hip(e, "clear rank counters");
+        }
+        ScopedTimer tm("eval_points", st);
+        e = launch_eval_side(&c.pts, nullptr, st);
+        if (e != hipSuccess) return fail_hip(e, "eval_points");
+    }
     if (phases & 2) {
         ScopedTimer tm("fused_tile_count", st);
-        e = launch_fused(MODE_COUNT, a, g.tiles, 1, st);
+        e = launch_fused(MODE_COUNT, c.sweep, c.g.tiles, 1, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<count>");
     }
     if (phases & 4) {
         ScopedTimer tm("eval_ranks", st);
-        e = launch_eval_ranks(a.rk_counts, a.rk_slab, g.tiles, tru, fx, filt_ptr, row_ptr, gshift, B, n_groups, ranks, acc, st);
+        e = launch_eval_side(nullptr, &c.rk, st);
         if (e != hipSuccess) return fail_hip(e, "eval_ranks");
     }
     return OKGE_OK;
+}
+
+static int evaluate_fused_impl(int phases, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
+                               const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
+                               const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
+                               void *workspace, size_t workspace_bytes, void *stream)
+{
+    EvalCall c;
+    if (int rc = eval_call(c, t, batch, cand, filt_ptr, filt_col, n_filter, row_ptr, grp_ptr, ids, n_groups, ranks, acc, workspace,
+                           workspace_bytes))
+        return rc;
+    return eval_issue(phases, c, reinterpret_cast<hipStream_t>(stream));
 }
 
 int okge_evaluate_fused(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
@@ -985,6 +1024,45 @@ int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_pr
     if (phase != 1 && phase != 2 && phase != 4) return fail(OKGE_ERR_INVALID, "phase must be 1 (points), 2 (sweep) or 4 (ranks)");
     return evaluate_fused_impl(phase, t, batch, cand, filt_ptr, filt_col, n_filter, row_ptr, grp_ptr, ids, n_groups, ranks, acc,
                                workspace, workspace_bytes, stream);
+}
+
+int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *batches, int32_t n_batches, int64_t *ranks,
+                                double *acc, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!batches || n_batches < 0 || !ranks || !acc || !workspace) return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
+    if (n_batches == 0) return OKGE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t half = (workspace_bytes / 2) & ~(size_t)255;
+    char *ws = static_cast<char *>(workspace);
+    // everything that can be refused is refused before the first launch; batches without answer groups have nothing to
+    // launch and drop out of the run
+    std::vector<EvalCall> calls;
+    calls.reserve((size_t)n_batches);
+    for (int i = 0; i < n_batches; ++i) {
+        const okge_eval_batch &b = batches[i];
+        if (b.rank_offset < 0) return fail(OKGE_ERR_INVALID, "negative rank_offset");
+        EvalCall c;
+        if (int rc = eval_call(c, t, &b.batch, &b.cand, b.filt_ptr, b.filt_col, b.n_filter, b.row_ptr, b.grp_ptr, b.ids, b.n_groups,
+                               ranks + b.rank_offset, acc, ws + (calls.size() & 1) * half, half))
+            return rc;
+        if (c.n_groups > 0) calls.push_back(c);
+    }
+    const int n = (int)calls.size();
+    if (n == 0) return OKGE_OK;
+    // one stream, two launches per batch: [points 0] [sweep 0] [ranks 0 + points 1] [sweep 1] [ranks 1 + points 2] ...
+    if (int rc = eval_issue(1, calls[0], st)) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = eval_issue(2, calls[i], st)) return rc;
+        const EvalCall *nx = i + 1 < n ? &calls[i + 1] : nullptr;
+        if (nx && !nx->eg.slab) {                              // (atomics path of very large batches: clear its counters)
+            hipError_t e = hipMemsetAsync(nx->counts, 0, (size_t)nx->n_groups * 2 * sizeof(int32_t), st);
+            if (e != hipSuccess) return fail_hip(e, "clear rank counters");
+        }
+        ScopedTimer tm("eval_ranks+points", st);
+        hipError_t e = launch_eval_side(nx ? &nx->pts : nullptr, &calls[i].rk, st);
+        if (e != hipSuccess) return fail_hip(e, "eval_side");
+    }
+    return OKGE_OK;
 }
 
 int okge_group_true_scores(const float *scores, int64_t ld_scores, int32_t B, int32_t col0, int32_t n_local,

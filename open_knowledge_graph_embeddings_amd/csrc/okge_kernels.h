@@ -124,13 +124,33 @@ hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, i
                                 int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_rank_metrics(const int64_t *ranks, int64_t n, double *acc, hipStream_t st);
 // fused evaluation (okge_evaluate_fused): point scores in the tile kernel's summation order, then ranks from the counts
-hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
-                              int KB, const int32_t *cand_ids, int cand_first, int n_cand, int64_t table_rows, const int64_t *row_ptr,
-                              const int64_t *grp_ptr, const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col,
-                              float *true_out, float *filt_x, int64_t *row_ptr_sorted, int64_t *gshift, hipStream_t st);
-hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int tiles, const float *true_scores, const float *filt_x, const int64_t *filt_ptr,
-                             const int64_t *row_ptr, const int64_t *gshift, int B, int64_t n_groups, int64_t *ranks, double *acc,
-                             hipStream_t st);
+// fused evaluation: the two small kernels around the tile sweep (okge_misc.hip)
+struct EvalPointsArgs {
+    const float   *E, *R;
+    PrefixDev      p;
+    float         *Q;                      // [Bpad][ldq] folded queries at their SORTED positions
+    const int32_t *cand_ids;
+    const int64_t *row_ptr, *grp_ptr, *filt_ptr;
+    const int32_t *ids, *filt_col;
+    float         *true_out, *filt_x;      // [n_groups] (sorted numbering), [n_filter]
+    int64_t       *row_ptr_sorted, *gshift;
+    int32_t       *group_row;              // [n_groups] row of every group (original numbering), for eval_ranks
+    int64_t        table_rows;
+    int32_t        d, scorer, ldq, KB, Bpad, cand_first, n_cand;
+};
+struct EvalRanksArgs {
+    const int32_t  *counts;                // [n_groups][2] (atomics path) or nullptr
+    const uint32_t *slab;                  // [tiles][n_groups] packed counts or nullptr
+    const float    *true_scores, *filt_x;
+    const int64_t  *filt_ptr, *gshift;
+    const int32_t  *group_row;
+    int64_t        *ranks;
+    double         *acc;
+    int64_t         n_groups;
+    int32_t         tiles, B;
+};
+// either part may be absent (nullptr): points of one batch and ranks of ANOTHER share a launch in a run of batches
+hipError_t launch_eval_side(const EvalPointsArgs *pts, const EvalRanksArgs *rk, hipStream_t st);
 hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, int col0, const float *true_in, float *true_out, int64_t *counts_out,

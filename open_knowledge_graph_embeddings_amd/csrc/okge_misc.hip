@@ -9,42 +9,9 @@
 
 #include "okge_device.h"
 #include "okge_kernels.h"
+#include "okge_eval_device.h"
 
 namespace okge {
-
-struct RowSrc {
-    int64_t ent, rel;   // ent: row in the LOCAL entity table (global id - ent_lo); valid only if owned
-    uint32_t pos;
-    bool sp, owned;
-};
-
-// Entity rows are sharded by id: this rank holds global ids [ent_lo, ent_hi) as local rows 0 .. ent_hi-ent_lo-1.
-__device__ __forceinline__ RowSrc row_source(const PrefixDev &p, int b)
-{
-    RowSrc r;
-    int64_t gid;
-    if (b < p.n_po) {
-        r.rel = p.po_rel[b]; gid = p.po_obj[b]; r.pos = (uint32_t)b; r.sp = false;
-    } else {
-        const int i = b - p.n_po;
-        gid = p.sp_subj[i]; r.rel = p.sp_rel[i]; r.pos = (uint32_t)i; r.sp = true;
-    }
-    r.owned = gid >= p.ent_lo && gid < p.ent_hi;
-    r.ent = gid - p.ent_lo;
-    int *err = threadIdx.x == 0 ? p.id_err : nullptr;
-    if (!r.owned && (p.whole_table || gid < 0) && err) atomicAdd(err, 1);   // not "another rank's row": a bad id
-    r.rel = checked_row(r.rel, p.n_rel, err);
-    return r;
-}
-
-// ComplEx query fold, written with explicit roundings (no fma contraction) so that every kernel that folds the same
-// masked rows produces the same bits:  sp [s1 r1 - s2 r2 , s2 r1 + s1 r2]   po [o1 r1 + o2 r2 , o2 r1 - o1 r2]
-__device__ __forceinline__ void fold_complex(bool sp, float e1, float e2, float r1, float r2, float &q1, float &q2)
-{
-    const float a = __fmul_rn(e1, r1), b = __fmul_rn(e2, r2), c = __fmul_rn(e2, r1), dd = __fmul_rn(e1, r2);
-    q1 = sp ? __fsub_rn(a, b) : __fadd_rn(a, b);
-    q2 = sp ? __fadd_rn(c, dd) : __fsub_rn(c, dd);
-}
 
 // One folded query row (and / or its masked entity row): gather + dropout + fold.  All threads of the workgroup take part.
 __device__ __forceinline__ void encode_query_row(const float *__restrict__ E, const float *__restrict__ R, int d, int scorer,
@@ -800,156 +767,14 @@ __global__ __launch_bounds__(256) void merge_lse_kernel(const float *__restrict_
     out[b] = m > -INFINITY ? m + logf(sacc) : -INFINITY;
 }
 
-// ---- fused evaluation (okge_evaluate_fused) ----------------------------------------------------------------------
-// score(b, n) exactly as fused_tile_kernel<KB, MODE_SCORE/MODE_COUNT> computes it: v_mfma_f32_16x16x4_f32 is a
-// k-ordered fp32 fma chain (MI355X guide), and the tile kernel feeds it k = 16r + 4s + j in the order r, j, s -- so a
-// scalar fmaf chain in that order gives the same bits.  Columns >= d hold zeros on both sides: fma(0, 0, acc) == acc.
-__device__ __forceinline__ float point_score(const float *__restrict__ q /* LDS, zero padded to 16*KB */,
-                                             const float *__restrict__ row, int d, int KB, bool vec_ok)
+// ---- fused evaluation (okge_evaluate_fused): the side work (okge_eval_device.h) ------------------------------------
+// The two small kernels of the fused evaluation in ONE launch: workgroups [0, n_points) take the rows of `pts`, the rest
+// the groups of `rk`.  In a run of batches the points of batch i+1 ride with the ranks of batch i (independent work of
+// two batches; either part may be empty).
+__global__ __launch_bounds__(256) void eval_side_kernel(const EvalPointsArgs pts, const EvalRanksArgs rk, int n_points)
 {
-    float acc = 0.f;
-    for (int r = 0; r < KB; ++r) {
-        float cv[16];
-        if (vec_ok && 16 * r + 16 <= d) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float4 v = *reinterpret_cast<const float4 *>(row + 16 * r + 4 * m);
-                cv[4 * m] = v.x; cv[4 * m + 1] = v.y; cv[4 * m + 2] = v.z; cv[4 * m + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 16; ++m) cv[m] = 16 * r + m < d ? row[16 * r + m] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) acc = __fmaf_rn(q[16 * r + 4 * sl + j], cv[4 * sl + j], acc);
-    }
-    return acc;
-}
-
-// One workgroup per batch row: the folded query row (-> Q for the tile sweep, and LDS), then the POINT scores the rank
-// rule needs besides the sweep's counts: each answer group's true score = max over its ids (dataset.py:436), and the
-// score under every filter entry (they are replaced by -1e8, dataset.py:441: corrected in eval_ranks_kernel).
-//
-// The sweep sees the batch SORTED BY GROUP COUNT (descending, stable): its counting loop runs as long as the busiest of a
-// wave's 16 rows, so rows with many answers are put together (measured: 2.4x fewer loop iterations at a mean of 1.8
-// groups per row).  Every workgroup finds its own row's position by counting the rows in front of it -- O(B) loads,
-// no sort kernel, no extra launch: pos = #{ng' > ng} + #{b' < b, ng' == ng}; the sorted CSR offset is the same sum over
-// ng'.  Q row, true scores and the sorted row_ptr go to the sorted positions; gshift[b] maps a group index back.
-__global__ __launch_bounds__(256) void eval_points_kernel(const float *__restrict__ E, const float *__restrict__ R, int d,
-                                                          int scorer, const PrefixDev p, float *__restrict__ Q, int ldq,
-                                                          int KB, const int32_t *__restrict__ cand_ids, int cand_first,
-                                                          int n_cand, int64_t table_rows,
-                                                          const int64_t *__restrict__ row_ptr,
-                                                          const int64_t *__restrict__ grp_ptr,
-                                                          const int32_t *__restrict__ ids,
-                                                          const int64_t *__restrict__ filt_ptr,
-                                                          const int32_t *__restrict__ filt_col,
-                                                          float *__restrict__ true_out, float *__restrict__ filt_x,
-                                                          int64_t *__restrict__ row_ptr_sorted, int64_t *__restrict__ gshift)
-{
-    __shared__ float qs[512];
-    __shared__ int red_pos[4];
-    __shared__ long long red_start[4];
-    const int b = blockIdx.x, B = p.n_po + p.n_sp;
-    // position of this row in the order sorted by group count, and the first sorted group index of the row
-    int pos = b;
-    int64_t start = 0, g_lo = 0, g_hi = 0;
-    if (b < B) {
-        g_lo = row_ptr[b]; g_hi = row_ptr[b + 1];
-        const int64_t ng = g_hi - g_lo;
-        int cnt = 0;
-        long long sum = 0;
-        for (int o = threadIdx.x; o < B; o += blockDim.x) {
-            const int64_t ngo = row_ptr[o + 1] - row_ptr[o];
-            const bool before = ngo > ng || (ngo == ng && o < b);
-            cnt += before;
-            sum += before ? ngo : 0;
-        }
-        cnt = wave_sum(cnt);
-        sum = (long long)wave_sum((double)sum);              // exact: group counts are far below 2^53
-        if ((threadIdx.x & 63) == 0) { red_pos[threadIdx.x >> 6] = cnt; red_start[threadIdx.x >> 6] = sum; }
-        __syncthreads();
-        pos = red_pos[0] + red_pos[1] + red_pos[2] + red_pos[3];
-        start = red_start[0] + red_start[1] + red_start[2] + red_start[3];
-        if (threadIdx.x == 0) {
-            row_ptr_sorted[pos] = start;
-            if (pos == B - 1) row_ptr_sorted[B] = start + ng;
-            gshift[b] = start - g_lo;
-        }
-    }
-    encode_query_row(E, R, d, scorer, p, b, qs, nullptr, 16 * KB);
-    __syncthreads();            // the row was written column-strided by other threads
-    for (int k = threadIdx.x; k < ldq; k += blockDim.x) Q[(size_t)pos * ldq + k] = k < 16 * KB ? qs[k] : 0.f;
-    if (b >= B) return;
-    const bool vec_ok = (d & 3) == 0;
-    auto cand_row = [&](int col) {            // col: a position in the candidate list (checked), then an entity row (checked)
-        col = (int)checked_row(col, n_cand, p.id_err);
-        const int64_t cid = checked_row(cand_ids ? (int64_t)cand_ids[col] : (int64_t)cand_first + col, table_rows, p.id_err);
-        return E + cid * d;
-    };
-    for (int64_t g = g_lo + threadIdx.x; g < g_hi; g += blockDim.x) {
-        float t = -INFINITY;
-        for (int64_t j = grp_ptr[g]; j < grp_ptr[g + 1]; ++j) t = fmaxf(t, point_score(qs, cand_row(ids[j]), d, KB, vec_ok));
-        true_out[g + (start - g_lo)] = t;                    // sorted group index
-    }
-    const int64_t f_lo = filt_ptr[b], f_hi = filt_ptr[b + 1];
-    for (int64_t f = f_lo + threadIdx.x; f < f_hi; f += blockDim.x) filt_x[f] = point_score(qs, cand_row(filt_col[f]), d, KB, vec_ok);
-}
-
-// One wave per answer group: rank = #greater + #equal / 2 from the sweep's counts, after replacing the scores under the
-// row's filter entries by -1e8 (dataset.py:441-446); then the meters of compute_metrics (dataset.py:447-452) are added
-// to acc[7] (double atomics: a handful per workgroup).
-__global__ __launch_bounds__(256) void eval_ranks_kernel(const int32_t *__restrict__ counts, const uint32_t *__restrict__ slab,
-                                                         int tiles, const float *__restrict__ true_scores,
-                                                         const float *__restrict__ filt_x, const int64_t *__restrict__ filt_ptr,
-                                                         const int64_t *__restrict__ row_ptr, const int64_t *__restrict__ gshift,
-                                                         int B, int64_t n_groups, int64_t *__restrict__ ranks,
-                                                         double *__restrict__ acc)
-{
-    __shared__ double red[4][7];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t g = (int64_t)blockIdx.x * 4 + w;
-    double v[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (g < n_groups) {
-        int lo = 0, hi = B;                              // the row that owns group g: row_ptr[row] <= g < row_ptr[row + 1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (row_ptr[mid] <= g) lo = mid; else hi = mid;
-        }
-        const int64_t gs = g + gshift[lo];               // the group's index in the sweep's (sorted) numbering
-        const float t = true_scores[gs];
-        int gt = 0, eq = 0;
-        for (int64_t f = filt_ptr[lo] + lane; f < filt_ptr[lo + 1]; f += 64) {
-            const float x = filt_x[f];
-            gt += (-1e8f > t) - (x > t);
-            eq += (-1e8f == t) - (x == t);
-        }
-        if (slab)                                        // the sweep's per-tile packed counts of this group
-            for (int tl = lane; tl < tiles; tl += 64) {
-                const uint32_t pk = slab[(size_t)tl * n_groups + gs];
-                gt += (int)(pk & 0xFFFFu);
-                eq += (int)(pk >> 16);
-            }
-        gt = wave_sum(gt);
-        eq = wave_sum(eq);
-        if (lane == 0) {
-            const int64_t r = (int64_t)(slab ? 0 : counts[2 * gs]) + gt + ((int64_t)(slab ? 0 : counts[2 * gs + 1]) + eq) / 2;
-            ranks[g] = r;
-            v[0] = 1.0;
-            v[1] = (double)(1.0f / (float)(r + 1));       // fp32 reciprocal like the reference's (1/(rank+1).float())
-            v[2] = (double)r;
-            v[3] = r < 1; v[4] = r < 3; v[5] = r < 10; v[6] = r < 50;
-        }
-    }
-    if (lane == 0)
-        for (int k = 0; k < 7; ++k) red[w][k] = v[k];
-    __syncthreads();
-    if (threadIdx.x < 7) {
-        const double tsum = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (tsum != 0.0) atomicAdd(acc + threadIdx.x, tsum);
-    }
+    if ((int)blockIdx.x < n_points) eval_points_block(pts, blockIdx.x);
+    else eval_ranks_block(rk, (int)blockIdx.x - n_points);
 }
 
 // ---- launchers -----------------------------------------------------------------------------------------
@@ -1104,24 +929,14 @@ hipError_t launch_ranks(const float *scores, int64_t ld, int B, int N, const int
 
 namespace okge {
 
-hipError_t launch_eval_points(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q, int ldq, int Bpad,
-                              int KB, const int32_t *cand_ids, int cand_first, int n_cand, int64_t table_rows, const int64_t *row_ptr,
-                              const int64_t *grp_ptr, const int32_t *ids, const int64_t *filt_ptr, const int32_t *filt_col,
-                              float *true_out, float *filt_x, int64_t *row_ptr_sorted, int64_t *gshift, hipStream_t st)
+hipError_t launch_eval_side(const EvalPointsArgs *pts, const EvalRanksArgs *rk, hipStream_t st)
 {
-    if (Bpad <= 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_points_kernel, dim3(Bpad), dim3(256), 0, st, E, R, d, scorer, p, Q, ldq, KB, cand_ids, cand_first,
-                       n_cand, table_rows, row_ptr, grp_ptr, ids, filt_ptr, filt_col, true_out, filt_x, row_ptr_sorted, gshift);
-    return hipGetLastError();
-}
-
-hipError_t launch_eval_ranks(const int32_t *counts, const uint32_t *slab, int tiles, const float *true_scores, const float *filt_x,
-                             const int64_t *filt_ptr, const int64_t *row_ptr, const int64_t *gshift, int B, int64_t n_groups,
-                             int64_t *ranks, double *acc, hipStream_t st)
-{
-    if (n_groups <= 0) return hipSuccess;
-    hipLaunchKernelGGL(eval_ranks_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, st, counts, slab, tiles, true_scores, filt_x,
-                       filt_ptr, row_ptr, gshift, B, n_groups, ranks, acc);
+    const int n_points = pts ? pts->Bpad : 0;
+    const int n_ranks = rk && rk->n_groups > 0 ? (int)((rk->n_groups + 3) / 4) : 0;
+    if (n_points + n_ranks <= 0) return hipSuccess;
+    static const EvalPointsArgs no_pts = {};
+    static const EvalRanksArgs no_rk = {};
+    hipLaunchKernelGGL(eval_side_kernel, dim3(n_points + n_ranks), dim3(256), 0, st, pts ? *pts : no_pts, rk ? *rk : no_rk, n_points);
     return hipGetLastError();
 }
 

@@ -25,81 +25,61 @@ def _meters(a):
 
 
 class FusedEvaluator:
-    """The evaluation loop on okge_evaluate_fused: per batch three launches (point scores, tile sweep with in-register
-    counting, ranks + meters), no (B, N) score block, no host read until the end.  The sweep runs on the current
-    stream; the two small latency-bound kernels run on a side stream, software-pipelined so that batch i+1's point
-    scores and batch i-1's ranks execute beside batch i's sweep (two workspaces / rank buffers alternate).  Slot sizes
+    """The evaluation loop on okge_evaluate_fused_batches: no (B, N) score block, no host read until the end, one stream,
+    two launches per batch -- the tile sweep with in-register counting, then one small launch holding the ranks + meters
+    of that batch and the point scores of the next.  The library issues a run of batches per call (`run_len`; the first
+    runs are short so that the device starts early).  (Round 2 first pipelined the small kernels on a second stream
+    beside the sweep: every cross-stream wait cost ~10 us of queue latency, more than the kernels it hid.)  Slot sizes
     up to 256, eval mode; PipelinedEvaluator (materialised scores) covers the rest."""
 
-    def __init__(self, E, R, scorer, engine=None):
+    def __init__(self, E, R, scorer, engine=None, run_len=32):
         self.E, self.R, self.scorer = E, R, scorer
         self.device = E.device
         self.engine = engine or H.HotPath(self.device)
-        self.side = torch.cuda.Stream(device=self.device)
-        self._ws = [None, None]
-        self._ranks = [None, None]
+        self.run_len = int(run_len)
+        self._ws = None
+        self._ranks = None
         self._t = self.engine._tables(E, R, scorer)
-        # two events per slot, created once (a fresh hipEvent per batch cost ~1 ms each until torch's pool had filled)
-        self._ev_pts = [torch.cuda.Event(), torch.cuda.Event()]
-        self._ev_swept = [torch.cuda.Event(), torch.cuda.Event()]
+        self._arr = (N.EvalBatch * self.run_len)()
 
-    def _args(self, cb, slot, acc):
+    def _fill(self, slot, cb):
         eng, b = self.engine, cb.batch
         pb, c, keep = eng._batch(b)
         n_groups, n_filter = int(cb.grp_ptr.numel()) - 1, int(cb.filt_col.numel())
+        x = self._arr[slot]
+        x.batch, x.cand = pb, c
+        x.filt_ptr, x.filt_col, x.n_filter = cb.filt_ptr.data_ptr(), (cb.filt_col.data_ptr() if n_filter else None), n_filter
+        x.row_ptr, x.grp_ptr, x.ids, x.n_groups = cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(), cb.ids.data_ptr(), n_groups
         need = int(eng.lib.okge_eval_workspace_bytes(b.B, c.n, self._t.d, n_groups, n_filter))
-        if self._ws[slot] is None or self._ws[slot].numel() < need:
-            self.side.synchronize()
-            self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
-            self._ws[slot].record_stream(self.side)
-        if self._ranks[slot] is None or self._ranks[slot].numel() < n_groups:
-            self.side.synchronize()
-            self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
-            self._ranks[slot].record_stream(self.side)
-        # (the batch's tensors are read on the side stream too: run() keeps every batch referenced until both streams
-        #  have drained instead of paying ten record_stream calls per batch)
-        return (ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c), cb.filt_ptr.data_ptr(),
-                cb.filt_col.data_ptr() if n_filter else None, n_filter, cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(),
-                cb.ids.data_ptr(), n_groups, self._ranks[slot].data_ptr(), acc.data_ptr(), self._ws[slot].data_ptr(),
-                self._ws[slot].numel()), (pb, c, keep)
+        return need, n_groups, keep
+
+    def _issue(self, n, need, n_groups, acc, stream_h):
+        # (one stream: a buffer that grows is freed in stream order by torch's allocator, after the kernels using it)
+        half = (need + 255) // 256 * 256
+        if self._ws is None or self._ws.numel() < 2 * half:
+            self._ws = torch.empty(2 * half, dtype=torch.uint8, device=self.device)
+        if self._ranks is None or self._ranks.numel() < 2 * n_groups:
+            self._ranks = torch.empty(max(2 * n_groups, 2048), dtype=torch.int64, device=self.device)
+        for i in range(n):                                   # the ranks themselves are scratch here: two regions alternate
+            self._arr[i].rank_offset = (i & 1) * n_groups
+        N.check(self.engine.lib.okge_evaluate_fused_batches(ctypes.byref(self._t), self._arr, n, self._ranks.data_ptr(),
+                                                            acc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream_h),
+                "okge_evaluate_fused_batches")
 
     def run(self, batches):
         """batches: iterable of dataset.CollatedBatch built with is_training_data=False -> (MetricResult, #groups)"""
-        lib = self.engine.lib
         acc = torch.zeros(7, dtype=torch.float64, device=self.device)
-        main = torch.cuda.current_stream(self.device)
-        side_h, main_h = ctypes.c_void_p(self.side.cuda_stream), ctypes.c_void_p(main.cuda_stream)
-        self.side.wait_stream(main)                         # tables / batches were produced on the current stream
-        it = iter(batches)
-        cur = next(it, None)
-        i, keep_alive = 0, []
-        if cur is None:
-            return _meters(acc.cpu().tolist())
-        cur_args, ka = self._args(cur, 0, acc)
-        keep_alive.append((ka, cur))
-        N.check(lib.okge_evaluate_fused_phase(1, *cur_args, side_h), "okge_evaluate_fused_phase(points)")
-        pts = self._ev_pts[0]
-        pts.record(self.side)
-        while cur is not None:
-            main.wait_event(pts)
-            N.check(lib.okge_evaluate_fused_phase(2, *cur_args, main_h), "okge_evaluate_fused_phase(sweep)")
-            swept = self._ev_swept[i & 1]
-            swept.record(main)
-            nxt = next(it, None)
-            if nxt is not None:                              # next batch's point scores go in BEFORE this batch's ranks
-                nxt_args, ka = self._args(nxt, (i + 1) & 1, acc)
-                keep_alive.append((ka, nxt))
-                N.check(lib.okge_evaluate_fused_phase(1, *nxt_args, side_h), "okge_evaluate_fused_phase(points)")
-                pts = self._ev_pts[(i + 1) & 1]
-                pts.record(self.side)
-            self.side.wait_event(swept)
-            N.check(lib.okge_evaluate_fused_phase(4, *cur_args, side_h), "okge_evaluate_fused_phase(ranks)")
-            cur, cur_args = nxt, (nxt_args if nxt is not None else None)
-            i += 1
-        main.wait_stream(self.side)
-        out = _meters(acc.cpu().tolist())          # (synchronises: every kernel that read a batch has finished)
-        del keep_alive
-        return out
+        stream_h = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        n, need, n_groups, run = 0, 0, 0, min(2, self.run_len)
+        for cb in batches:
+            nd, ng, _ = self._fill(n, cb)                    # (everything is issued on the current stream: the caching
+            need, n_groups, n = max(need, nd), max(n_groups, ng), n + 1     # allocator keeps the batch's tensors valid)
+            if n == run:
+                self._issue(n, need, n_groups, acc, stream_h)
+                n, need, n_groups, run = 0, 0, 0, min(2 * run, self.run_len)
+        if n:
+            self._issue(n, need, n_groups, acc, stream_h)
+        return _meters(acc.cpu().tolist())
 
 
 class PipelinedEvaluator:

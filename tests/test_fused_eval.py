@@ -139,3 +139,58 @@ def test_fused_evaluator_equals_pipelined(okge_lib):
     assert na == nb and na > 0
     for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
         assert abs(a[k].avg - b[k].avg) <= 1e-12 * max(1.0, abs(b[k].avg)), k
+    for run_len in (1, 2):                                     # run boundaries: 5 batches as 1+1+1+1+1 and 2+2+1
+        c, nc = FusedEvaluator(Et, Rt, "complex", run_len=run_len).run(iter(cbs))
+        assert nc == na
+        for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
+            assert c[k].avg == a[k].avg, (run_len, k)
+
+
+def test_fused_batches_ranks_equal_single_calls(okge_lib):
+    """okge_evaluate_fused_batches with every batch's ranks kept (rank_offset = prefix sum of the group counts) ==
+    okge_evaluate_fused batch by batch, bit for bit; refusals happen before the first launch"""
+    import ctypes
+    import torch
+    from open_knowledge_graph_embeddings_amd import _native as NV
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.dataset import CollatedBatch
+    from open_knowledge_graph_embeddings_amd.evaluate import FusedEvaluator
+    rng = np.random.default_rng(11)
+    n_ent, d = 1500, 64
+    E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal((12, d)) * 0.3).astype(np.float32)
+    Et, Rt = _dev(E), _dev(R)
+    hp = H.HotPath(Et.device)
+    cbs, want = [], []
+    for k in range(7):
+        _, _, batch, csr, N = _case(rng, n_ent, 12, d, 11 + 9 * k, 40 - 5 * k, "complex", 2 + k % 3, False, cand_list=k == 4)
+        dd = {kk: _dev(v) for kk, v in csr.items()}
+        cbs.append(CollatedBatch(batch, 1.0, 1.0, N, row_ptr=dd["row_ptr"], grp_ptr=dd["grp_ptr"], ids=dd["ids"],
+                                 filt_ptr=dd["filt_ptr"], filt_col=dd["filt_col"]))
+        r, _ = hp.evaluate_fused(Et, Rt, "complex", batch, dd["filt_ptr"], dd["filt_col"], dd["row_ptr"], dd["grp_ptr"], dd["ids"])
+        want.append(r.cpu().numpy().copy())
+    fe = FusedEvaluator(Et, Rt, "complex", engine=hp, run_len=len(cbs))
+    need, off, keep = 0, 0, []
+    for i, cb in enumerate(cbs):
+        nd, ng, ka = fe._fill(i, cb)
+        keep.append(ka)
+        need = max(need, nd)
+        fe._arr[i].rank_offset = off
+        off += ng
+    half = (need + 255) // 256 * 256
+    ws = torch.empty(2 * half, dtype=torch.uint8, device=Et.device)
+    ranks = torch.full((off,), -7, dtype=torch.int64, device=Et.device)
+    acc = torch.zeros(7, dtype=torch.float64, device=Et.device)
+    main = ctypes.c_void_p(torch.cuda.current_stream(Et.device).cuda_stream)
+    args = (ctypes.byref(fe._t), fe._arr, len(cbs), ranks.data_ptr(), acc.data_ptr(), ws.data_ptr())
+    rc = hp.lib.okge_evaluate_fused_batches(*args, ws.numel(), main)
+    NV.check(rc, "okge_evaluate_fused_batches")
+    torch.cuda.synchronize()
+    got = ranks.cpu().numpy()
+    assert np.array_equal(got, np.concatenate(want))
+    assert int(acc[0].item()) == off
+    # too small a workspace: refused before the first launch, nothing written
+    ranks.fill_(-7)
+    assert hp.lib.okge_evaluate_fused_batches(*args, half, main) != 0
+    torch.cuda.synchronize()
+    assert int((ranks != -7).sum().item()) == 0
