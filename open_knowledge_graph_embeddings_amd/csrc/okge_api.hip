@@ -1026,13 +1026,30 @@ int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_pr
                                workspace, workspace_bytes, stream);
 }
 
+// events of okge_evaluate_fused_batches (fork / join of the second stream), created once per process
+static hipError_t eval_events(hipEvent_t **out)
+{
+    static hipEvent_t ev[2];
+    static bool ready = false;
+    if (!ready) {
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        ready = true;
+    }
+    *out = ev;
+    return hipSuccess;
+}
+
 int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *batches, int32_t n_batches, int64_t *ranks,
-                                double *acc, void *workspace, size_t workspace_bytes, void *stream)
+                                double *acc, void *workspace, size_t workspace_bytes, void *stream, void *stream2)
 {
     if (!batches || n_batches < 0 || !ranks || !acc || !workspace) return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
     if (n_batches == 0) return OKGE_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const size_t half = (workspace_bytes / 2) & ~(size_t)255;
+    hipStream_t st[2] = {reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipStream_t>(stream2 ? stream2 : stream)};
+    const bool two = st[0] != st[1];
+    const size_t quarter = (workspace_bytes / 4) & ~(size_t)255;
     char *ws = static_cast<char *>(workspace);
     // everything that can be refused is refused before the first launch; batches without answer groups have nothing to
     // launch and drop out of the run
@@ -1043,25 +1060,44 @@ int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *bat
         if (b.rank_offset < 0) return fail(OKGE_ERR_INVALID, "negative rank_offset");
         EvalCall c;
         if (int rc = eval_call(c, t, &b.batch, &b.cand, b.filt_ptr, b.filt_col, b.n_filter, b.row_ptr, b.grp_ptr, b.ids, b.n_groups,
-                               ranks + b.rank_offset, acc, ws + (calls.size() & 1) * half, half))
+                               ranks + b.rank_offset, acc, ws + (calls.size() & 3) * quarter, quarter))
             return rc;
         if (c.n_groups > 0) calls.push_back(c);
     }
     const int n = (int)calls.size();
     if (n == 0) return OKGE_OK;
-    // one stream, two launches per batch: [points 0] [sweep 0] [ranks 0 + points 1] [sweep 1] [ranks 1 + points 2] ...
-    if (int rc = eval_issue(1, calls[0], st)) return rc;
-    for (int i = 0; i < n; ++i) {
-        if (int rc = eval_issue(2, calls[i], st)) return rc;
-        const EvalCall *nx = i + 1 < n ? &calls[i + 1] : nullptr;
-        if (nx && !nx->eg.slab) {                              // (atomics path of very large batches: clear its counters)
-            hipError_t e = hipMemsetAsync(nx->counts, 0, (size_t)nx->n_groups * 2 * sizeof(int32_t), st);
-            if (e != hipSuccess) return fail_hip(e, "clear rank counters");
-        }
-        ScopedTimer tm("eval_ranks+points", st);
-        hipError_t e = launch_eval_side(nx ? &nx->pts : nullptr, &calls[i].rk, st);
-        if (e != hipSuccess) return fail_hip(e, "eval_side");
+    // Batch i runs on stream i & 1; each stream is an independent chain [points i] [sweep i] [ranks i + points i+2]
+    // [sweep i+2] ... with no dependency on the other, so the device fills one chain's small latency-bound launches with
+    // the other chain's sweep.  Four workspace slots: two batches in flight per chain.
+    hipEvent_t *ev = nullptr;
+    hipError_t e = hipSuccess;
+#define OKGE_EV(call, what) do { e = (call); if (e != hipSuccess) return fail_hip(e, what); } while (0)
+    if (two) {
+        OKGE_EV(eval_events(&ev), "create evaluation events");
+        OKGE_EV(hipEventRecord(ev[0], st[0]), "record fork");          // the second stream joins behind whatever produced
+        OKGE_EV(hipStreamWaitEvent(st[1], ev[0], 0), "fork");          // the tables / batches on the first
     }
+    auto clear_counts = [&](const EvalCall &c, hipStream_t s) {      // (atomics path of very large batches only)
+        return c.eg.slab ? hipSuccess : hipMemsetAsync(c.counts, 0, (size_t)c.n_groups * 2 * sizeof(int32_t), s);
+    };
+    for (int i = 0; i < n; ++i) {
+        hipStream_t s = st[i & 1];
+        if (i < 2) {                                                   // head of a chain
+            OKGE_EV(clear_counts(calls[i], s), "clear rank counters");
+            ScopedTimer tm("eval_points", s);
+            OKGE_EV(launch_eval_side(&calls[i].pts, nullptr, s), "eval_points");
+        }
+        if (int rc = eval_issue(2, calls[i], s)) return rc;
+        const EvalCall *nx = i + 2 < n ? &calls[i + 2] : nullptr;      // the chain's next batch
+        if (nx) OKGE_EV(clear_counts(*nx, s), "clear rank counters");
+        ScopedTimer tm("eval_ranks+points", s);
+        OKGE_EV(launch_eval_side(nx ? &nx->pts : nullptr, &calls[i].rk, s), "eval_side");
+    }
+    if (two) {
+        OKGE_EV(hipEventRecord(ev[1], st[1]), "record join");
+        OKGE_EV(hipStreamWaitEvent(st[0], ev[1], 0), "join");
+    }
+#undef OKGE_EV
     return OKGE_OK;
 }
 

@@ -10,7 +10,7 @@ namespace okge {
 constexpr int NT = 64;             // candidate rows per tile
 constexpr int BC = 64;             // batch rows per chunk
 constexpr int LDG = 68;            // leading dimension of the 64x64 G / X tile in LDS (4*odd)
-constexpr int FUSED_THREADS = 256; // 4 waves, one per SIMD
+constexpr int FUSED_THREADS = 512; // 8 waves, two per SIMD (fused_tile_kernel: score / stats / count sweep)
 constexpr int POS_CACHE = 512;     // positives of one candidate tile cached in LDS (more spill to global reads)
 
 enum { MODE_TRAIN_BCE = 0, MODE_SCORE = 1, MODE_STATS = 2, MODE_TRAIN_KL = 3, MODE_COUNT = 4 };

@@ -36,57 +36,55 @@ namespace okge {
 // keepb (LDS, [NT][32] bytes) caches the keep flags for the dC epilogue; Cm (global [NT][16*KB]) receives the
 // masked tile for dq_kernel.  Either may be nullptr.
 template <int KB>
-__device__ __forceinline__ void load_cand_tile(float *Cs, uint8_t *keepb, float *Cm, const float *__restrict__ E,
-                                               int d, const int32_t *__restrict__ cand_ids, int cand_first, int N,
-                                               int n0, const DropDev &drop, bool vec_ok, int tid, int cand_col0,
-                                               int64_t table_rows, int *id_err)
+__device__ __forceinline__ void load_cand_tile(float *Cs, const float *__restrict__ E, int d, const int32_t *__restrict__ cand_ids,
+                                               int cand_first, int N, int n0, const DropDev &drop, bool vec_ok, int tid,
+                                               int cand_col0, int64_t table_rows, int *id_err)
 {
+    // 512 threads: row r = tid / 8, column group tid % 8 (octets o = tid % 8 + 8 it)
     constexpr int LDK = lds_ld(16 * KB), NO = 2 * KB, NOIT = (NO + 7) / 8;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int r = (tid >> 3) + 32 * pass;
-        const int n = n0 + r;
-        const bool valid = n < N;
-        int64_t cid = 0;
-        if (valid) cid = checked_row(cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n, table_rows, (tid & 7) ? nullptr : id_err);
-        const float *row = E + cid * d;
-        float4 v0[NOIT], v1[NOIT];
+    const int r = tid >> 3, n = n0 + r;
+    const bool valid = n < N;
+    int64_t cid = 0;
+    if (valid) cid = checked_row(cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n, table_rows, (tid & 7) ? nullptr : id_err);
+    const float *row = E + cid * d;
+    float4 v0[NOIT], v1[NOIT];
+    if (vec_ok) {
+        // branch-free: the 2 NOIT 16-byte loads of a thread go out back to back (out-of-range pieces re-read the row's
+        // first floats and are zeroed below)
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
             const int o = (tid & 7) + 8 * it, k = 8 * o;
-            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            v1[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o < NO && valid && k < d) {
-                if (vec_ok) {
-                    v0[it] = *reinterpret_cast<const float4 *>(row + k);
-                    if (k + 4 < d) v1[it] = *reinterpret_cast<const float4 *>(row + k + 4);
-                } else {
-                    float t[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = (k + e < d) ? row[k + e] : 0.f;
-                    v0[it] = make_float4(t[0], t[1], t[2], t[3]);
-                    v1[it] = make_float4(t[4], t[5], t[6], t[7]);
-                }
-            }
+            const bool in0 = o < NO && valid && k < d, in1 = in0 && k + 4 < d;
+            v0[it] = *reinterpret_cast<const float4 *>(row + (in0 ? k : 0));
+            v1[it] = *reinterpret_cast<const float4 *>(row + (in1 ? k + 4 : 0));
         }
+    } else {
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
             const int o = (tid & 7) + 8 * it, k = 8 * o;
-            if (o < NO) {
-                uint32_t bits = 0xFFu;
-                if (drop.enabled) {
-                    bits = (valid && k < d) ? drop_keep8(drop, (uint32_t)(n + cand_col0), o, d) : 0u;
-                    apply_keep4(v0[it], bits & 15u, drop.scale);
-                    apply_keep4(v1[it], bits >> 4, drop.scale);
-                }
-                *reinterpret_cast<float4 *>(Cs + r * LDK + k) = v0[it];
-                *reinterpret_cast<float4 *>(Cs + r * LDK + k + 4) = v1[it];
-                if (keepb) keepb[r * 32 + o] = (uint8_t)bits;
-                if (Cm) {
-                    *reinterpret_cast<float4 *>(Cm + (size_t)r * (16 * KB) + k) = v0[it];
-                    *reinterpret_cast<float4 *>(Cm + (size_t)r * (16 * KB) + k + 4) = v1[it];
-                }
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (o < NO && valid && k + e < d) ? row[k + e] : 0.f;
+            v0[it] = make_float4(t[0], t[1], t[2], t[3]);
+            v1[it] = make_float4(t[4], t[5], t[6], t[7]);
+        }
+    }
+    const uint32_t dstep = drop.enabled ? drop_step(drop) : 0u;
+#pragma unroll
+    for (int it = 0; it < NOIT; ++it) {
+        const int o = (tid & 7) + 8 * it, k = 8 * o;
+        if (o < NO) {
+            const bool in0 = valid && k < d, in1 = in0 && k + 4 < d;
+            uint32_t bits = in0 ? 0xFFu : 0u;
+            if (drop.enabled && in0) bits = drop_keep8(drop, (uint32_t)(n + cand_col0), o, d, dstep);
+            if (!in0) v0[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!in1) v1[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (drop.enabled) {
+                apply_keep4(v0[it], bits & 15u, drop.scale);
+                apply_keep4(v1[it], bits >> 4, drop.scale);
             }
+            *reinterpret_cast<float4 *>(Cs + r * LDK + k) = v0[it];
+            *reinterpret_cast<float4 *>(Cs + r * LDK + k + 4) = v1[it];
         }
     }
 }
@@ -151,46 +149,54 @@ __device__ __forceinline__ int grad_col(int kbi, int c)
     return kbi < 4 * KQ ? 64 * (kbi >> 2) + 4 * c + (kbi & 3) : 64 * KQ + 16 * (kbi - 4 * KQ) + c;
 }
 
+// Score / stats / count sweep of one 64-candidate tile over the batch in chunks of 64 rows: ONE 8-wave workgroup per CU
+// (the 64 x LDK candidate tile + query chunk fill the LDS), two waves per SIMD.  Wave w: rows 16 (w & 3) .. + 15 of
+// the chunk, candidate blocks 2 (w >> 2) and 2 (w >> 2) + 1 (the query operand is shared by the two).  (Round 1-2: four
+// waves, one per SIMD, each with all four candidate blocks: nothing overlapped a wave's LDS reads, epilogue VALU and
+// barriers, and the sweep sat at 0.43 of the MFMA peak.)
 template <int KB, int MODE>
 __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LDK = lds_ld(16 * KB);
+    constexpr int NBW = 2;                                    // candidate blocks per wave
     const int d = a.d;
     float *Cs = reinterpret_cast<float *>(smem);              // [NT][LDK]
     float *Qs = Cs + NT * LDK;                                // [BC][LDK]
-    float *Xs = Qs + BC * LDK;                                // [BC][LDG]   X tile staging (score mode)
+    float *Xs = Qs + BC * LDK;                                // [BC][LDG]   X tile staging (score mode), counters, stats partials
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, s = lane >> 4;
+    const int wq = w & 3, nh = w >> 2;
     const int n0 = blockIdx.x * NT;
     const int b_begin = blockIdx.y * a.b_per_block;
     const int b_end = min(a.B, b_begin + a.b_per_block);
     const bool vec_ok = (d & 3) == 0;
 
-    // register-staged query chunk: thread (row r = tid/4, quarter q = tid%4) holds KB float4 of that row
-    const int qr = tid >> 2, qq = tid & 3;
-    v4f qreg[KB];
+    // register-staged query chunk: thread (row r = tid/8, eighth q = tid%8) holds float4 q + 8 it of that row
+    constexpr int NQ = 4 * KB, NQIT = (NQ + 7) / 8;
+    const int qr = tid >> 3, qq = tid & 7;
+    v4f qreg[NQIT];
     auto fetch_chunk = [&](int b0) {
         const int b = b0 + qr;
-        const float *src = a.Q + (size_t)b * a.ldq + 4 * qq;
+        const float *src = a.Q + (size_t)b * a.ldq;
 #pragma unroll
-        for (int it = 0; it < KB; ++it)
-            qreg[it] = (b < b_end) ? *reinterpret_cast<const v4f *>(src + 16 * it) : (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < NQIT; ++it) {
+            const int f = min(qq + 8 * it, NQ - 1);           // clamped: surplus lanes reload the last float4
+            qreg[it] = (b < b_end) ? *reinterpret_cast<const v4f *>(src + 4 * f) : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
     };
     fetch_chunk(b_begin);
-    load_cand_tile<KB>(Cs, nullptr, nullptr, a.E, d, a.cand_ids, a.cand_first, a.N, n0, a.drop_c, vec_ok, tid,
-                       a.cand_col0, a.n_table_rows, a.id_err);
+    load_cand_tile<KB>(Cs, a.E, d, a.cand_ids, a.cand_first, a.N, n0, a.drop_c, vec_ok, tid, a.cand_col0, a.n_table_rows, a.id_err);
 
     // MODE_COUNT: the group range of the lane's row is loaded ONE CHUNK AHEAD and the row's first RK_PRE true scores before
-    // the score product, so that the counting loop does not wait on dependent global loads (one workgroup of four
-    // waves per CU: nothing else would hide them)
+    // the score product, so that the counting loop does not wait on dependent global loads
     constexpr int RK_PRE = 4;
     int64_t rk_glo = 0, rk_glo_n = 0, rk_c0 = 0, rk_c1 = 0, rk_c0_n = 0, rk_c1_n = 0;
     int rk_ng = 0, rk_ng_n = 0;
     float rk_t[RK_PRE];
     auto rk_fetch_rows = [&](int b0) {
         if (MODE != MODE_COUNT) return;
-        const int b = b0 + 16 * w + c;
+        const int b = b0 + 16 * wq + c;
         rk_glo_n = 0; rk_ng_n = 0;
         if (b < b_end) {
             rk_glo_n = a.rk_row_ptr[b];
@@ -204,7 +210,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
     for (int b0 = b_begin; b0 < b_end; b0 += BC) {
         // ---- phase A: park the prefetched chunk in LDS, prefetch the next chunk -------------------------------
 #pragma unroll
-        for (int it = 0; it < KB; ++it) *reinterpret_cast<v4f *>(Qs + qr * LDK + 4 * qq + 16 * it) = qreg[it];
+        for (int it = 0; it < NQIT; ++it)
+            if (qq + 8 * it < NQ) *reinterpret_cast<v4f *>(Qs + qr * LDK + 4 * (qq + 8 * it)) = qreg[it];
         if (b0 + BC < b_end) fetch_chunk(b0 + BC);
         if (MODE == MODE_COUNT) {
             rk_glo = rk_glo_n; rk_ng = rk_ng_n;
@@ -219,48 +226,51 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
         }
         __syncthreads();
 
-        // ---- phase B: X = Q_chunk . C^T ; wave w owns rows 16w..16w+15, all four 16-wide n blocks -------------
-        v4f x[4];
+        // ---- phase B: X = Q_chunk . C^T ; wave w owns rows 16wq..16wq+15 x candidate blocks 2nh, 2nh+1 ----------
+        v4f x[NBW];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) x[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < NBW; ++nb) x[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
         {
-            // operands of round r+1 are requested before the 16 MFMAs of round r issue
-            const float *qa = Qs + (16 * w + c) * LDK + 4 * s;
-            const float *cb = Cs + c * LDK + 4 * s;
-            v4f av = *reinterpret_cast<const v4f *>(qa), bv[4];
+            // operands of round r+1 are requested before the MFMAs of round r issue
+            const float *qa = Qs + (16 * wq + c) * LDK + 4 * s;
+            const float *cb = Cs + (16 * NBW * nh + c) * LDK + 4 * s;
+            v4f av = *reinterpret_cast<const v4f *>(qa), bv[NBW];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) bv[nb] = *reinterpret_cast<const v4f *>(cb + 16 * nb * LDK);
-            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            for (int nb = 0; nb < NBW; ++nb) bv[nb] = *reinterpret_cast<const v4f *>(cb + 16 * nb * LDK);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1 + NBW, 0);
 #pragma unroll
             for (int r = 0; r < KB; ++r) {
-                v4f an = av, bn[4] = {bv[0], bv[1], bv[2], bv[3]};
+                v4f an = av, bn[NBW];
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) bn[nb] = bv[nb];
                 if (r + 1 < KB) {
                     an = *reinterpret_cast<const v4f *>(qa + 16 * (r + 1));
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) bn[nb] = *reinterpret_cast<const v4f *>(cb + 16 * nb * LDK + 16 * (r + 1));
+                    for (int nb = 0; nb < NBW; ++nb) bn[nb] = *reinterpret_cast<const v4f *>(cb + 16 * nb * LDK + 16 * (r + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
+                    for (int nb = 0; nb < NBW; ++nb)
                         x[nb] = MODE == MODE_COUNT ? mfma16(bv[nb][j], av[j], x[nb])     // X^T block: lane = batch row
                                                    : mfma16(av[j], bv[nb][j], x[nb]);
                 av = an;
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) bv[nb] = bn[nb];
-                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);    // 5 ds_read (next round)
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);   // 16 MFMA  (this round)
+                for (int nb = 0; nb < NBW; ++nb) bv[nb] = bn[nb];
+                __builtin_amdgcn_sched_group_barrier(0x100, 1 + NBW, 0);    // the ds_reads of the next round
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NBW, 0);    // the MFMAs of this round
             }
         }
-        // lane holds X[b = b0 + 16w + 4s + i][n = n0 + 16nb + c] in x[nb][i]
-        // (MODE_COUNT, operands swapped: X[b = b0 + 16w + c][n = n0 + 16nb + 4s + i] -- the same products in the same
-        //  order, a * b == b * a, so the same bits -- one batch row per lane)
+        // lane holds X[b = b0 + 16wq + 4s + i][n = n0 + 16(2nh + nb) + c] in x[nb][i]
+        // (MODE_COUNT, operands swapped: X[b = b0 + 16wq + c][n = n0 + 16(2nh + nb) + 4s + i] -- the same products in the
+        //  same order, a * b == b * a, so the same bits -- one batch row per lane)
+        const int nb0 = NBW * nh;                              // first candidate block of this wave
 
         if (MODE == MODE_SCORE) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) Xs[(16 * w + 4 * s + i) * LDG + 16 * nb + c] = x[nb][i];
+                for (int i = 0; i < 4; ++i) Xs[(16 * wq + 4 * s + i) * LDG + 16 * (nb0 + nb) + c] = x[nb][i];
             __syncthreads();
             for (int idx = tid; idx < BC * 16; idx += FUSED_THREADS) {
                 const int r = idx >> 4, c4 = idx & 15;
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
         } else if (MODE == MODE_COUNT) {
             // fused evaluation: compare the block against the true scores of each row's answer groups and add the
             // {#greater, #equal} of this tile to the group's counters; the (B, N) score block is never written.
-            // (dataset.py:436-446; the filter correction is applied by eval_ranks_kernel from point scores.)
+            // (dataset.py:436-446; the filter correction is applied by eval_ranks_block from point scores.)
             // The groups of a chunk's 64 rows are one contiguous index range: their packed counts (#greater | #equal << 16)
             // are summed in LDS and leave as one coalesced store per tile and chunk.  (Global atomics from a few lanes
             // per instruction cost ~100 cycles each and made this sweep 3.5x slower; with the untransposed block, 4 rows
@@ -291,73 +301,101 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
             const int64_t gc_lo = rk_c0, gc_hi = rk_c1;
             const bool in_lds = a.rk_slab && gc_hi - gc_lo <= CNT_CAP;
             uint32_t *slab_row = a.rk_slab ? a.rk_slab + (size_t)blockIdx.x * a.rk_ngroups : nullptr;
-            float xm[4][4];
+            float xm[NBW][4];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xm[nb][i] = n0 + 16 * nb + 4 * s + i < a.N ? x[nb][i] : -INFINITY;
+                for (int i = 0; i < 4; ++i) xm[nb][i] = n0 + 16 * (nb0 + nb) + 4 * s + i < a.N ? x[nb][i] : -INFINITY;
             const int64_t g_lo = rk_glo;
             const int ng = rk_ng;
-            for (int j = 0; __builtin_amdgcn_ballot_w64(j < ng) != 0; ++j) {
-                float t = j < ng && j >= RK_PRE ? a.rk_true[g_lo + j] : __builtin_nanf("");
+            // a row's 64 candidates of this tile sit in eight lanes: c, c+16, c+32, c+48 of the waves (wq, 0) and (wq, 1).
+            // Counters in LDS: all eight add atomically.  Otherwise (a chunk with more groups than the LDS tile holds, or
+            // the atomics path of very large batches): the wave pair takes turns -- first half stores, second half adds.
+            auto count_pass = [&](bool add) {
+                for (int j = 0; __builtin_amdgcn_ballot_w64(j < ng) != 0; ++j) {
+                    float t = j < ng && j >= RK_PRE ? a.rk_true[g_lo + j] : __builtin_nanf("");
 #pragma unroll
-                for (int jj = 0; jj < RK_PRE; ++jj) t = j == jj ? rk_t[jj] : t;
-                int pq[4] = {0, 0, 0, 0};                    // four independent chains: one wave per SIMD, nothing else
-                float mx = -INFINITY;                        // hides the compare -> add latency
+                    for (int jj = 0; jj < RK_PRE; ++jj) t = j == jj ? rk_t[jj] : t;
+                    int pq[NBW];
+                    float mx = -INFINITY;
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
+                    for (int nb = 0; nb < NBW; ++nb) {
+                        pq[nb] = 0;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        pq[nb] += xm[nb][i] > t;
-                        mx = fmaxf(mx, xm[nb][i] <= t ? xm[nb][i] : -INFINITY);      // largest score not above t
+                        for (int i = 0; i < 4; ++i) {
+                            pq[nb] += xm[nb][i] > t;
+                            mx = fmaxf(mx, xm[nb][i] <= t ? xm[nb][i] : -INFINITY);      // largest score not above t
+                        }
                     }
-                int pk = (pq[0] + pq[1]) + (pq[2] + pq[3]);
-                const bool any_eq = mx == t;
-                if (__builtin_amdgcn_ballot_w64(any_eq) != 0) {          // exact ties are rare (the true answer's own tile)
+                    int pk = pq[0] + pq[1];
+                    const bool any_eq = mx == t;
+                    if (__builtin_amdgcn_ballot_w64(any_eq) != 0) {      // exact ties are rare (the true answer's own tile)
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
+                        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) pk += xm[nb][i] == t ? 65536 : 0;
-                }
-                if (j < ng) {        // the row's 64 candidates of this tile sit in the four lanes c, c+16, c+32, c+48
-                    if (in_lds) {
-                        if (pk) atomicAdd(&cnt[g_lo + j - gc_lo], (uint32_t)pk);
-                    } else {
-                        pk += __shfl_xor(pk, 16);
-                        pk += __shfl_xor(pk, 32);
-                        if (s == 0) {
-                            if (slab_row) slab_row[g_lo + j] = (uint32_t)pk;
-                            else {
-                                if (pk & 0xFFFF) atomicAdd(a.rk_counts + 2 * (g_lo + j), pk & 0xFFFF);
-                                if (pk >> 16) atomicAdd(a.rk_counts + 2 * (g_lo + j) + 1, pk >> 16);
+                            for (int i = 0; i < 4; ++i) pk += xm[nb][i] == t ? 65536 : 0;
+                    }
+                    if (j < ng) {
+                        if (in_lds) {
+                            if (pk) atomicAdd(&cnt[g_lo + j - gc_lo], (uint32_t)pk);
+                        } else {
+                            pk += __shfl_xor(pk, 16);
+                            pk += __shfl_xor(pk, 32);
+                            if (s == 0) {
+                                if (slab_row) slab_row[g_lo + j] = add ? slab_row[g_lo + j] + (uint32_t)pk : (uint32_t)pk;
+                                else {
+                                    if (pk & 0xFFFF) atomicAdd(a.rk_counts + 2 * (g_lo + j), pk & 0xFFFF);
+                                    if (pk >> 16) atomicAdd(a.rk_counts + 2 * (g_lo + j) + 1, pk >> 16);
+                                }
                             }
                         }
                     }
                 }
-            }
-            __syncthreads();
-            if (in_lds)
+            };
+            if (in_lds) {
+                count_pass(false);
+                __syncthreads();
                 for (int k = tid; k < (int)(gc_hi - gc_lo); k += FUSED_THREADS) slab_row[gc_lo + k] = cnt[k];
+            } else {
+                if (nh == 0) count_pass(false);
+                __syncthreads();
+                if (nh == 1) count_pass(true);
+                __syncthreads();
+            }
         } else {
-            // MODE_STATS: per row of the chunk, max and sum-exp over this tile's candidates
+            // MODE_STATS: per row of the chunk, max and sum-exp over this tile's candidates: each wave reduces its 32
+            // candidates, the second wave of a row parks its pair in LDS and the first merges (running max / sum-exp)
+            float2 *part = reinterpret_cast<float2 *>(Xs);       // [BC]
+            float pm[4], pse[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float m = -INFINITY;
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    if (n0 + 16 * nb + c < a.N) m = fmaxf(m, x[nb][i]);
+                for (int nb = 0; nb < NBW; ++nb)
+                    if (n0 + 16 * (nb0 + nb) + c < a.N) m = fmaxf(m, x[nb][i]);
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
                 float se = 0.f;
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
-                    if (n0 + 16 * nb + c < a.N) se += __expf(x[nb][i] - m);
+                for (int nb = 0; nb < NBW; ++nb)
+                    if (n0 + 16 * (nb0 + nb) + c < a.N) se += __expf(x[nb][i] - m);
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
-                const int b = b0 + 16 * w + 4 * s + i;
-                if (c == 0 && b < b_end) {
-                    float2 *dst = reinterpret_cast<float2 *>(a.stats) + (size_t)blockIdx.x * a.Bpad + b;
-                    *dst = make_float2(m, se);
+                pm[i] = m; pse[i] = se;
+                if (nh == 1 && c == 0) part[16 * wq + 4 * s + i] = make_float2(m, se);
+            }
+            __syncthreads();
+            if (nh == 0 && c == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int b = b0 + 16 * wq + 4 * s + i;
+                    const float2 o = part[16 * wq + 4 * s + i];
+                    const float m = fmaxf(pm[i], o.x);
+                    const float se = (pm[i] > -INFINITY ? pse[i] * __expf(pm[i] - m) : 0.f) + (o.x > -INFINITY ? o.y * __expf(o.x - m) : 0.f);
+                    if (b < b_end) {
+                        float2 *dst = reinterpret_cast<float2 *>(a.stats) + (size_t)blockIdx.x * a.Bpad + b;
+                        *dst = make_float2(m, se);
+                    }
                 }
             }
             __syncthreads();

@@ -25,18 +25,20 @@ def _meters(a):
 
 
 class FusedEvaluator:
-    """The evaluation loop on okge_evaluate_fused_batches: no (B, N) score block, no host read until the end, one stream,
-    two launches per batch -- the tile sweep with in-register counting, then one small launch holding the ranks + meters
-    of that batch and the point scores of the next.  The library issues a run of batches per call (`run_len`; the first
-    runs are short so that the device starts early).  (Round 2 first pipelined the small kernels on a second stream
-    beside the sweep: every cross-stream wait cost ~10 us of queue latency, more than the kernels it hid.)  Slot sizes
-    up to 256, eval mode; PipelinedEvaluator (materialised scores) covers the rest."""
+    """The evaluation loop on okge_evaluate_fused_batches: no (B, N) score block, no host read until the end.  The library
+    issues a run of batches per call (`run_len`; the first runs are short so that the device starts early): even batches
+    on the current stream, odd ones on a second stream, each stream an independent chain of two launches per batch -- the
+    tile sweep with in-register counting, then one small launch holding the ranks + meters of that batch and the point
+    scores of the chain's next batch -- so one chain's small latency-bound launches run beside the other chain's sweep
+    without any per-batch cross-stream wait (those cost ~10 us each; round 2's first design paid one per batch).
+    Slot sizes up to 256, eval mode; PipelinedEvaluator (materialised scores) covers the rest."""
 
-    def __init__(self, E, R, scorer, engine=None, run_len=32):
+    def __init__(self, E, R, scorer, engine=None, run_len=32, two_streams=True):
         self.E, self.R, self.scorer = E, R, scorer
         self.device = E.device
         self.engine = engine or H.HotPath(self.device)
         self.run_len = int(run_len)
+        self.side = torch.cuda.Stream(device=self.device) if two_streams else None
         self._ws = None
         self._ranks = None
         self._t = self.engine._tables(E, R, scorer)
@@ -54,32 +56,41 @@ class FusedEvaluator:
         return need, n_groups, keep
 
     def _issue(self, n, need, n_groups, acc, stream_h):
-        # (one stream: a buffer that grows is freed in stream order by torch's allocator, after the kernels using it)
-        half = (need + 255) // 256 * 256
-        if self._ws is None or self._ws.numel() < 2 * half:
-            self._ws = torch.empty(2 * half, dtype=torch.uint8, device=self.device)
-        if self._ranks is None or self._ranks.numel() < 2 * n_groups:
-            self._ranks = torch.empty(max(2 * n_groups, 2048), dtype=torch.int64, device=self.device)
-        for i in range(n):                                   # the ranks themselves are scratch here: two regions alternate
-            self._arr[i].rank_offset = (i & 1) * n_groups
+        quarter = (need + 255) // 256 * 256
+        if self._ws is None or self._ws.numel() < 4 * quarter or self._ranks.numel() < 4 * n_groups:
+            self._ws = torch.empty(4 * max(quarter, 0 if self._ws is None else self._ws.numel() // 4), dtype=torch.uint8,
+                                   device=self.device)
+            self._ranks = torch.empty(max(4 * n_groups, 4096, 0 if self._ranks is None else self._ranks.numel()),
+                                      dtype=torch.int64, device=self.device)
+        for i in range(n):                                   # the ranks themselves are scratch here: four regions rotate
+            self._arr[i].rank_offset = (i & 3) * n_groups
+        side_h = ctypes.c_void_p(self.side.cuda_stream) if self.side is not None else None
+        # (the library orders the current stream behind the second stream's share at the end of every call; letting the
+        #  chains run on across calls instead measured no faster)
         N.check(self.engine.lib.okge_evaluate_fused_batches(ctypes.byref(self._t), self._arr, n, self._ranks.data_ptr(),
-                                                            acc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream_h),
-                "okge_evaluate_fused_batches")
+                                                            acc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream_h,
+                                                            side_h), "okge_evaluate_fused_batches")
 
     def run(self, batches):
         """batches: iterable of dataset.CollatedBatch built with is_training_data=False -> (MetricResult, #groups)"""
         acc = torch.zeros(7, dtype=torch.float64, device=self.device)
-        stream_h = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        main = torch.cuda.current_stream(self.device)
+        stream_h = ctypes.c_void_p(main.cuda_stream)
         n, need, n_groups, run = 0, 0, 0, min(2, self.run_len)
-        for cb in batches:
-            nd, ng, _ = self._fill(n, cb)                    # (everything is issued on the current stream: the caching
-            need, n_groups, n = max(need, nd), max(n_groups, ng), n + 1     # allocator keeps the batch's tensors valid)
+        keep = []                       # a run's tensors (and id conversions) stay referenced until it has been issued:
+        for cb in batches:              # after that the current stream's order protects them (see _issue)
+            nd, ng, ka = self._fill(n, cb)
+            keep.append((ka, cb))
+            need, n_groups, n = max(need, nd), max(n_groups, ng), n + 1
             if n == run:
                 self._issue(n, need, n_groups, acc, stream_h)
+                keep.clear()
                 n, need, n_groups, run = 0, 0, 0, min(2 * run, self.run_len)
         if n:
             self._issue(n, need, n_groups, acc, stream_h)
-        return _meters(acc.cpu().tolist())
+        out = _meters(acc.cpu().tolist())          # (synchronises: every kernel that read a batch has finished)
+        keep.clear()
+        return out
 
 
 class PipelinedEvaluator:

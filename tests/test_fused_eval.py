@@ -140,7 +140,7 @@ def test_fused_evaluator_equals_pipelined(okge_lib):
     for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
         assert abs(a[k].avg - b[k].avg) <= 1e-12 * max(1.0, abs(b[k].avg)), k
     for run_len in (1, 2):                                     # run boundaries: 5 batches as 1+1+1+1+1 and 2+2+1
-        c, nc = FusedEvaluator(Et, Rt, "complex", run_len=run_len).run(iter(cbs))
+        c, nc = FusedEvaluator(Et, Rt, "complex", run_len=run_len, two_streams=run_len == 2).run(iter(cbs))
         assert nc == na
         for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
             assert c[k].avg == a[k].avg, (run_len, k)
@@ -177,20 +177,22 @@ def test_fused_batches_ranks_equal_single_calls(okge_lib):
         need = max(need, nd)
         fe._arr[i].rank_offset = off
         off += ng
-    half = (need + 255) // 256 * 256
-    ws = torch.empty(2 * half, dtype=torch.uint8, device=Et.device)
+    quarter = (need + 255) // 256 * 256
+    ws = torch.empty(4 * quarter, dtype=torch.uint8, device=Et.device)
     ranks = torch.full((off,), -7, dtype=torch.int64, device=Et.device)
     acc = torch.zeros(7, dtype=torch.float64, device=Et.device)
     main = ctypes.c_void_p(torch.cuda.current_stream(Et.device).cuda_stream)
     args = (ctypes.byref(fe._t), fe._arr, len(cbs), ranks.data_ptr(), acc.data_ptr(), ws.data_ptr())
-    rc = hp.lib.okge_evaluate_fused_batches(*args, ws.numel(), main)
-    NV.check(rc, "okge_evaluate_fused_batches")
-    torch.cuda.synchronize()
-    got = ranks.cpu().numpy()
-    assert np.array_equal(got, np.concatenate(want))
-    assert int(acc[0].item()) == off
+    for second in (None, ctypes.c_void_p(fe.side.cuda_stream)):          # one stream; two independent chains
+        ranks.fill_(-7)
+        acc.zero_()
+        torch.cuda.synchronize()
+        NV.check(hp.lib.okge_evaluate_fused_batches(*args, ws.numel(), main, second), "okge_evaluate_fused_batches")
+        torch.cuda.synchronize()
+        assert np.array_equal(ranks.cpu().numpy(), np.concatenate(want))
+        assert int(acc[0].item()) == off
     # too small a workspace: refused before the first launch, nothing written
     ranks.fill_(-7)
-    assert hp.lib.okge_evaluate_fused_batches(*args, half, main) != 0
+    assert hp.lib.okge_evaluate_fused_batches(*args, 3 * quarter, main, None) != 0
     torch.cuda.synchronize()
     assert int((ranks != -7).sum().item()) == 0
