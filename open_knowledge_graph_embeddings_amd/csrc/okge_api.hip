@@ -931,7 +931,8 @@ static int eval_call(EvalCall &c, const okge_tables *t, const okge_prefix_batch 
                      void *workspace, size_t workspace_bytes)
 {
     if (int rc = check_common(t, batch, cand)) return rc;
-    if (!filt_ptr || !row_ptr || !grp_ptr || !ids || !ranks || !acc || n_groups < 0 || n_filter < 0 || (n_filter > 0 && !filt_col))
+    if (!filt_ptr || !row_ptr || !grp_ptr || (n_groups > 0 && !ids) || !ranks || !acc || n_groups < 0 || n_filter < 0 ||
+        (n_filter > 0 && !filt_col))                      // (a batch without answer groups has no ids array)
         return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
     if (t->d > 256) return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation covers slot sizes up to 256: use okge_evaluate_batch");
     if (cand->table || cand->drop.p > 0.f || batch->drop_po_ent.p > 0.f || batch->drop_sp_ent.p > 0.f ||

@@ -196,3 +196,30 @@ def test_fused_batches_ranks_equal_single_calls(okge_lib):
     assert hp.lib.okge_evaluate_fused_batches(*args, 3 * quarter, main, None) != 0
     torch.cuda.synchronize()
     assert int((ranks != -7).sum().item()) == 0
+
+
+def test_fused_run_with_empty_and_one_direction_batches(okge_lib):
+    """a run whose batches include one without any answer group (nothing to launch: it drops out of its chain), one with
+    po rows only and one with sp rows only: meters equal the materialising evaluator's"""
+    from open_knowledge_graph_embeddings_amd.dataset import CollatedBatch
+    from open_knowledge_graph_embeddings_amd.evaluate import FusedEvaluator, PipelinedEvaluator
+    rng = np.random.default_rng(23)
+    n_ent, d = 700, 128
+    E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal((15, d)) * 0.3).astype(np.float32)
+    Et, Rt = _dev(E), _dev(R)
+    cbs = []
+    for k, (n_po, n_sp) in enumerate(((20, 20), (0, 33), (17, 9), (41, 0), (8, 8), (12, 30))):
+        _, _, batch, csr, N = _case(rng, n_ent, 15, d, n_po, n_sp, "complex", 3, False)
+        if k in (2, 4):                                   # no answer groups at all in this batch
+            B = n_po + n_sp
+            csr = dict(csr, row_ptr=np.zeros(B + 1, np.int64), grp_ptr=np.zeros(1, np.int64), ids=np.zeros(0, np.int32))
+        dd = {kk: _dev(v) for kk, v in csr.items()}
+        cbs.append(CollatedBatch(batch, 1.0, 1.0, N, row_ptr=dd["row_ptr"], grp_ptr=dd["grp_ptr"], ids=dd["ids"],
+                                 filt_ptr=dd["filt_ptr"], filt_col=dd["filt_col"]))
+    b, nb = PipelinedEvaluator(Et, Rt, "complex").run([cb for k, cb in enumerate(cbs) if k not in (2, 4)])
+    for two in (True, False):
+        a, na = FusedEvaluator(Et, Rt, "complex", run_len=8, two_streams=two).run(cbs)
+        assert na == nb and na > 0
+        for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
+            assert abs(a[k].avg - b[k].avg) <= 1e-12 * max(1.0, abs(b[k].avg)), (two, k)
