@@ -40,11 +40,31 @@ __device__ __forceinline__ void encode_query_row(const float *__restrict__ E, co
         }
     } else {
         const int h = d >> 1;
-        for (int k = threadIdx.x; k < h; k += blockDim.x) {
-            const float e1 = e[k] * drop_mult1(de, rs.pos, k, d), e2 = e[h + k] * drop_mult1(de, rs.pos, h + k, d);
-            const float r1 = r[k] * drop_mult1(dr, rs.pos, k, d), r2 = r[h + k] * drop_mult1(dr, rs.pos, h + k, d);
-            if (q) fold_complex(rs.sp, e1, e2, r1, r2, q[k], q[h + k]);
-            if (er) { er[k] = e1; er[h + k] = e2; }
+        if ((h & 3) == 0 && (de.enabled || dr.enabled)) {
+            // The four threads of an aligned column quad need the same four keep octets -- columns k and h + k of the
+            // entity and of the relation mask (h % 4 == 0: a quad never straddles an octet) -- so each computes ONE of
+            // them (a Philox call) and they trade by shuffles, instead of four Philox calls per thread.
+            const int role = threadIdx.x & 3, lane0 = (threadIdx.x & 63) & ~3;
+            for (int k = threadIdx.x; k < h; k += blockDim.x) {
+                const float ve1 = e[k], ve2 = e[h + k], vr1 = r[k], vr2 = r[h + k];     // requested before the mask arithmetic
+                const DropDev &dd = (role & 2) ? dr : de;
+                const int kc = (role & 1) ? h + k : k;
+                const uint32_t mine = dd.enabled ? drop_keep8(dd, rs.pos, kc >> 3, d) : 0xFFu;
+                const uint32_t b_e1 = __shfl(mine, lane0), b_e2 = __shfl(mine, lane0 + 1);
+                const uint32_t b_r1 = __shfl(mine, lane0 + 2), b_r2 = __shfl(mine, lane0 + 3);
+                auto mult = [](const DropDev &x, uint32_t bits, int col) { return !x.enabled ? 1.f : (bits >> (col & 7) & 1u) ? x.scale : 0.f; };
+                const float e1 = ve1 * mult(de, b_e1, k), e2 = ve2 * mult(de, b_e2, h + k);
+                const float r1 = vr1 * mult(dr, b_r1, k), r2 = vr2 * mult(dr, b_r2, h + k);
+                if (q) fold_complex(rs.sp, e1, e2, r1, r2, q[k], q[h + k]);
+                if (er) { er[k] = e1; er[h + k] = e2; }
+            }
+        } else {
+            for (int k = threadIdx.x; k < h; k += blockDim.x) {
+                const float e1 = e[k] * drop_mult1(de, rs.pos, k, d), e2 = e[h + k] * drop_mult1(de, rs.pos, h + k, d);
+                const float r1 = r[k] * drop_mult1(dr, rs.pos, k, d), r2 = r[h + k] * drop_mult1(dr, rs.pos, h + k, d);
+                if (q) fold_complex(rs.sp, e1, e2, r1, r2, q[k], q[h + k]);
+                if (er) { er[k] = e1; er[h + k] = e2; }
+            }
         }
     }
     for (int k = d + threadIdx.x; k < ldq; k += blockDim.x) {
