@@ -177,15 +177,19 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.tile_w = g.KB <= 16 ? 64 : 32;
     g.tile_w = env_int("OKGE_TILE_W", g.tile_w) == 32 ? 32 : g.tile_w;      // diagnostic: the round-1 cut
     g.ktiles = g.tiles * (NT / g.tile_w);
-    const int slots = g.tile_w == 64 ? 256 : 512;
-    // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y.  The split that minimises
-    // (rounds of workgroups over the slots) x (row blocks per workgroup); ties go to the coarser split (fewer slabs).
+    const int slots = (g.tile_w == 64 || g.KB > 16) ? 256 : 512;       // one workgroup per CU, except the 32-wide cut at d <= 256
+    // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y.  Cost of a split into c:
+    // (rounds of workgroups over the slots) x (row blocks per workgroup + 1) -- the "+ 1" is a workgroup's fixed cost, the
+    // candidate gather and the gradient write-back, about one 64-row block (profiles/round2_ablation.md §1) -- plus the c
+    // partial-gradient slabs dc_reduce adds up (an eighth of a block each).  Measured at cfg3 (313 tiles of 32, d = 512):
+    // c = 1 / 2 / 3 / 4 / 8 -> 0.299 / 0.288 / 0.294 / 0.303 / 0.364 ms per step; the model orders them 18 / 15 / 16 / 15 / 20.
     int bs = 1;
-    if (g.ktiles < slots * 3 / 4) {
+    {
         long best = -1;
         for (int c = 1; c <= bblks; ++c) {
             const long rounds = ((long)g.ktiles * c + slots - 1) / slots, per = (bblks + c - 1) / c;
-            if (best < 0 || rounds * per < best) { best = rounds * per; bs = c; }
+            const long cost = 8 * rounds * (per + 1) + c;
+            if (best < 0 || cost < best) { best = cost; bs = c; }
         }
     }
     bs = std::max(1, env_int("OKGE_B_SPLIT", bs));
