@@ -118,6 +118,31 @@ __device__ __forceinline__ int64_t checked_row(int64_t id, int64_t n_rows, int *
     return id;
 }
 
+// Reductions over the 16 lanes of a DPP row (lanes 16s .. 16s+15) with DPP moves instead of ds_bpermute shuffles: quad
+// swaps (xor 1, xor 2), then row_half_mirror and row_mirror -- after the quad steps all four lanes of a quad agree, so
+// the mirrors pair every quad with the one it still misses.  All 16 lanes end up with the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v)
+{
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

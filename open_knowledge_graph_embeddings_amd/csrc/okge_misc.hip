@@ -300,11 +300,10 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         }
-#pragma unroll
-        for (int o = 1; o < 4; o <<= 1) {
-            acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o);
-            acc.z += __shfl_xor(acc.z, o); acc.w += __shfl_xor(acc.w, o);
-        }
+        // the four lanes of a column group are a DPP quad: xor 1, xor 2 as quad permutes (a ds_bpermute shuffle each
+        // would cost ~60 cycles on this latency-bound path)
+        acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y); acc.z += dpp_mov<0xB1>(acc.z); acc.w += dpp_mov<0xB1>(acc.w);
+        acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y); acc.z += dpp_mov<0x4E>(acc.z); acc.w += dpp_mov<0x4E>(acc.w);
         return acc;
     };
     // The keep nibbles of a column group: lane sq computes ONE of the (up to four) Philox calls the group needs and the

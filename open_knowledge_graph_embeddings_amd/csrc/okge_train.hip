@@ -76,7 +76,7 @@ __device__ __forceinline__ void load_cand_tile(float *Cs, const float *__restric
         if (o < NO) {
             const bool in0 = valid && k < d, in1 = in0 && k + 4 < d;
             uint32_t bits = in0 ? 0xFFu : 0u;
-            if (drop.enabled && in0) bits = drop_keep8(drop, (uint32_t)(n + cand_col0), o, d, dstep);
+            if (drop.enabled && in0) bits = drop_keep8<true>(drop, (uint32_t)(n + cand_col0), o, d, dstep);
             if (!in0) v0[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!in1) v1[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (drop.enabled) {
@@ -373,14 +373,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_tile_kernel(const FusedAr
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb)
                     if (n0 + 16 * (nb0 + nb) + c < a.N) m = fmaxf(m, x[nb][i]);
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+                m = row16_max(m);
                 float se = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < NBW; ++nb)
                     if (n0 + 16 * (nb0 + nb) + c < a.N) se += __expf(x[nb][i] - m);
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
+                se = row16_sum(se);
                 pm[i] = m; pse[i] = se;
                 if (nh == 1 && c == 0) part[16 * wq + 4 * s + i] = make_float2(m, se);
             }

@@ -266,11 +266,9 @@ __global__ __launch_bounds__(Tile32Cfg<KB>::THREADS, Tile32Cfg<KB>::WAVES_PER_SI
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float m = nvalid ? x[i] : -INFINITY;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+                m = row16_max(m);
                 float se = nvalid ? __expf(x[i] - m) : 0.f;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
+                se = row16_sum(se);
                 const int b = b0 + 16 * half + 4 * s + i;
                 if (ks == 0 && c == 0 && b < b_end)
                     reinterpret_cast<float2 *>(a.stats)[(size_t)(2 * blockIdx.x + nbk) * a.Bpad + b] = make_float2(m, se);
