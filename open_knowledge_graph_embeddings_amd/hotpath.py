@@ -16,6 +16,8 @@ from typing import Optional
 
 import torch
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
 from . import _native as N
 
 
@@ -156,7 +158,10 @@ class HotPath:
 
     # -- plumbing ------------------------------------------------------------------------------------
     def _stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # the raw handle of torch's current stream on this device (torch.cuda.current_stream builds a Stream object:
+        # ~5 us per call, and every library call asks)
+        idx = self.device.index
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
 
     def workspace(self, B, n_cand, d, kind="train"):
         """scratch for one call; kind 'score' (query block only) and 'lse' are much smaller than 'train'"""

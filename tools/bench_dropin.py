@@ -104,3 +104,4 @@ if os.environ.get("OKGE_PROFILE_DROPIN") == "1":
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(24)
