@@ -82,8 +82,8 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
     const int d = a.d;
     float *Cs = reinterpret_cast<float *>(smem);              // [64][LDK]
     float *Qs = Cs + NT64 * LDK;                              // [64][LDK]
-    uint32_t *ybits2 = reinterpret_cast<uint32_t *>(Qs + BC64 * LDK);    // [2][2 halves][64 rows] label bits, double-buffered
-    double *red = reinterpret_cast<double *>(ybits2 + 2 * BC64 * 2);     // [8]
+    uint32_t *ybits3 = reinterpret_cast<uint32_t *>(Qs + BC64 * LDK);    // [3][2 halves][64 rows] label bits, three chunks in rotation
+    double *red = reinterpret_cast<double *>(ybits3 + 3 * BC64 * 2);     // [8]
     uint8_t *keepb = reinterpret_cast<uint8_t *>(red + 8);               // [64][KEEP_LD] keep flags of the tile
     uint32_t *posc = reinterpret_cast<uint32_t *>(keepb + NT64 * KEEP_LD);   // [POS_CACHE] (row << 6 | col)
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
         // (after the mask arithmetic: vmcnt retires in order, so waiting for these loads waits for the rows as well)
         for (int i = tid; i < pos_cached; i += T64_THREADS)
             posc[i] = ((uint32_t)a.pos_row[pos_lo + i] << 6) | (uint32_t)(a.pos_col[pos_lo + i] - a.cand_col0 - n0);
-        if (tid < 2 * BC64 * 2) ybits2[tid] = 0u;
+        if (tid < 3 * BC64 * 2) ybits3[tid] = 0u;
 #pragma unroll
         for (int it = 0; it < NOIT; ++it) {
             const int o = q8 + QG * it, k = 8 * o;
@@ -199,33 +199,46 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
     };
     int cm_done = 0;
 
+    // Label bits of a chunk (bit = candidate column of the tile, word = candidate half x batch row) from the tile's positives.
+    // Three buffers in rotation: chunk i's bits are SET while chunk i-1's score product runs (they need no barrier of their
+    // own: two lie between the set and the epilogue that reads them) and the buffer chunk i-1 used is cleared then too --
+    // in the staging phase, between the two barriers of a chunk, nothing overlaps these dependent LDS round trips.
+    auto set_label_bits = [&](int bb, uint32_t *yb) {
+        for (int i = tid; i < pos_cached; i += T64_THREADS) {
+            const uint32_t v = posc[i];
+            const int row = (int)(v >> 6) - bb;
+            if (row >= 0 && row < BC64) atomicOr(&yb[BC64 * ((v >> 5) & 1u) + row], 1u << (v & 31u));
+        }
+        for (int q = pos_lo + POS_CACHE + tid; q < pos_hi; q += T64_THREADS) {      // overflow: rare
+            const int row = a.pos_row[q] - bb;
+            const int col = a.pos_col[q] - a.cand_col0 - n0;
+            if (row >= 0 && row < BC64) atomicOr(&yb[BC64 * (col >> 5) + row], 1u << (col & 31));
+        }
+    };
+    set_label_bits(b_begin, ybits3);        // chunk 0 (the three buffers were cleared before the prologue's barrier)
     int par = 0;
-    for (int b0 = b_begin; b0 < b_end; b0 += BC64, par ^= 1) {
-        // ---- phase A: park the prefetched chunk, set label bits, prefetch the next chunk ------------------------
-        // (no barrier separates a wave's epilogue from its dC product, so the label bits are double-buffered: this
-        //  chunk's buffer was cleared one chunk ago, the previous chunk's buffer is cleared now)
-        uint32_t *ybits = ybits2 + par * (2 * BC64);
+    for (int b0 = b_begin; b0 < b_end; b0 += BC64, par = par == 2 ? 0 : par + 1) {
+        // ---- phase A: park the prefetched chunk, prefetch the next chunk -----------------------------------------
+        uint32_t *ybits = ybits3 + par * (2 * BC64);
+        TL_STAMP_AT(48 + ((b0 - b_begin) >> 6));   // chunk entered (the previous chunk's closing barrier passed)
 #pragma unroll
         for (int it = 0; it < NQIT; ++it) {
             const int q = q8 + QG * it;
             if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
         }
-        if (tid < 2 * BC64) ybits2[(par ^ 1) * (2 * BC64) + tid] = 0u;
-        for (int i = tid; i < pos_cached; i += T64_THREADS) {
-            const uint32_t v = posc[i];
-            const int row = (int)(v >> 6) - b0;
-            if (row >= 0 && row < BC64) atomicOr(&ybits[BC64 * ((v >> 5) & 1u) + row], 1u << (v & 31u));
-        }
-        for (int q = pos_lo + POS_CACHE + tid; q < pos_hi; q += T64_THREADS) {      // overflow: rare
-            const int row = a.pos_row[q] - b0;
-            const int col = a.pos_col[q] - a.cand_col0 - n0;
-            if (row >= 0 && row < BC64) atomicOr(&ybits[BC64 * (col >> 5) + row], 1u << (col & 31));
-        }
+        TL_STAMP_AT(56 + ((b0 - b_begin) >> 6));   // query chunk parked
+        TL_STAMP_AT(64 + ((b0 - b_begin) >> 6));   // label bits set
         if (b0 + BC64 < b_end) fetch_chunk(b0 + BC64);
-        if (b0 > b_begin && cm_done < NOIT) write_cm(cm_done++);
+        TL_STAMP_AT(72 + ((b0 - b_begin) >> 6));   // next chunk requested
         TL_STAMP();   // [0] staged, before the barrier
         __syncthreads();
         TL_STAMP();   // [1] start of score product
+        {   // under the score product: the next chunk's label bits, the buffer after that cleared, one group of masked rows out
+            const int pn = par == 2 ? 0 : par + 1, pc = pn == 2 ? 0 : pn + 1;
+            if (tid < 2 * BC64) ybits3[pc * (2 * BC64) + tid] = 0u;
+            if (b0 + BC64 < b_end) set_label_bits(b0 + BC64, ybits3 + pn * (2 * BC64));
+            if (b0 > b_begin && cm_done < NOIT) write_cm(cm_done++);
+        }
 
         // ---- score blocks (rows 32h + 16rg + 4s + i, columns 16blk + c), rg = 0, 1 -----------------------------------
         v4f x0 = (v4f){0.f, 0.f, 0.f, 0.f}, x1 = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -475,7 +488,7 @@ template <int KB>
 static size_t shmem64()
 {
     using Cfg = Tile64Cfg<KB>;
-    return (size_t)(NT64 + BC64) * Cfg::LDK * sizeof(float) + 2 * BC64 * 2 * sizeof(uint32_t) + 8 * sizeof(double) +
+    return (size_t)(NT64 + BC64) * Cfg::LDK * sizeof(float) + 3 * BC64 * 2 * sizeof(uint32_t) + 8 * sizeof(double) +
            NT64 * Cfg::KEEP_LD + POS_CACHE * sizeof(uint32_t);
 }
 

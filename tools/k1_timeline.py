@@ -41,6 +41,12 @@ if tile_w == 64:
             print(f"{ch:3d}  {r[0]:7d} {r[1]:7d} {r[2]:7d} {r[3]:7d} | {r[2]-r[1]:6d} {r[3]-r[2]:6d} {r[1]-r[0]:6d} "
                   f"{(r[1]-prev) if prev is not None else 0:6d}")
             prev = r[1]
+        print("staging of each chunk: entered (closing barrier passed) -> queries parked -> label bits -> next chunk requested -> staged (masked rows out)")
+        for ch in range(8):
+            r = [tl[wg, 48 + ch], tl[wg, 56 + ch], tl[wg, 64 + ch], tl[wg, 72 + ch], tl[wg, 4 * ch]]
+            if min(r) > 0:
+                r = [x - base for x in r]
+                print(f"{ch:3d}  {r[0]:7d} +{r[1]-r[0]:5d} +{r[2]-r[1]:5d} +{r[3]-r[2]:5d} +{r[4]-r[3]:5d}")
         print("loop done at", tl[wg, 32] - base)
         pe = tl[wg, 40:45] - base
         print(f"prologue: gather loads issued {pe[0]}, tile parked in LDS {pe[1]}, barrier passed {pe[2]}")
