@@ -63,7 +63,12 @@ template <int KB> struct Tile64Cfg {
 #define TL_STAMP_AT(idx) do { } while (0)
 #endif
 
-template <int KB, int MODE>
+// REGC (slot sizes up to 208): every lane keeps its slice of the wave's candidate block -- the B operand of the whole
+// score sweep, KB float4 -- in registers, read from the gathered tile once.  The tile's LDS then serves as a SECOND query
+// chunk buffer: chunk i+1 is parked while chunk i is being worked on, so a chunk has ONE barrier and no staging phase
+// (with one buffer every wave parks, requests and waits between two barriers while the MFMA pipes idle: ~1.3 K of a
+// chunk's 17.9 K cycles), and the score product reads a third less from LDS.
+template <int KB, int MODE, bool REGC>
 __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const FusedArgs a)
 {
 #ifdef OKGE_STAMPS
@@ -173,6 +178,11 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
                 *reinterpret_cast<v4f *>(Cs + r8 * LDK + k) = v0[it];
                 *reinterpret_cast<v4f *>(Cs + r8 * LDK + k + 4) = v1[it];
                 keepb[r8 * KEEP_LD + o] = (uint8_t)bits[it];
+                if (REGC && blockIdx.y == 0 && !a.loss_only) {        // the masked rows for dq_kernel, straight from the registers
+                    float *cm = a.Cm + (size_t)(n0 + r8) * (16 * KB);  // (the tile's LDS is reused before a later chunk could)
+                    *reinterpret_cast<v4f *>(cm + k) = v0[it];
+                    *reinterpret_cast<v4f *>(cm + k + 4) = v1[it];
+                }
             }
         }
     }
@@ -198,6 +208,20 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
         }
     };
     int cm_done = 0;
+    // REGC: the lane's candidate operand (row 16blk + c, columns 16r + 4s .. + 3 of every round r) into registers and the
+    // first query chunk parked -- then the tile's LDS is free for the odd chunks
+    v4f breg[REGC ? KB : 1];
+    if (REGC) {
+#pragma unroll
+        for (int r = 0; r < KB; ++r) breg[r] = *reinterpret_cast<const v4f *>(Cs + (16 * blk + c) * LDK + 16 * r + 4 * s);
+        cm_done = NOIT;                 // (written in the prologue)
+#pragma unroll
+        for (int it = 0; it < NQIT; ++it) {
+            const int q = q8 + QG * it;
+            if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
+        }
+        if (b_begin + BC64 < b_end) fetch_chunk(b_begin + BC64);
+    }
 
     // Label bits of a chunk (bit = candidate column of the tile, word = candidate half x batch row) from the tile's positives.
     // Three buffers in rotation: chunk i's bits are SET while chunk i-1's score product runs (they need no barrier of their
@@ -218,50 +242,55 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
     set_label_bits(b_begin, ybits3);        // chunk 0 (the three buffers were cleared before the prologue's barrier)
     int par = 0;
     for (int b0 = b_begin; b0 < b_end; b0 += BC64, par = par == 2 ? 0 : par + 1) {
-        // ---- phase A: park the prefetched chunk, prefetch the next chunk -----------------------------------------
         uint32_t *ybits = ybits3 + par * (2 * BC64);
+        // query chunk buffer of this chunk / of the next (REGC: the two LDS tiles alternate)
+        float *Qc = REGC && (((b0 - b_begin) >> 6) & 1) ? Cs : Qs;
+        float *Qn = REGC ? (Qc == Qs ? Cs : Qs) : Qs;
         TL_STAMP_AT(48 + ((b0 - b_begin) >> 6));   // chunk entered (the previous chunk's closing barrier passed)
+        if (!REGC) {
+            // ---- phase A: park the prefetched chunk, prefetch the next chunk -------------------------------------
 #pragma unroll
-        for (int it = 0; it < NQIT; ++it) {
-            const int q = q8 + QG * it;
-            if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
+            for (int it = 0; it < NQIT; ++it) {
+                const int q = q8 + QG * it;
+                if (q < NQ) *reinterpret_cast<v4f *>(Qs + r8 * LDK + 4 * q) = qreg[it];
+            }
+            TL_STAMP_AT(56 + ((b0 - b_begin) >> 6));   // query chunk parked
+            if (b0 + BC64 < b_end) fetch_chunk(b0 + BC64);
+            TL_STAMP_AT(72 + ((b0 - b_begin) >> 6));   // next chunk requested
         }
-        TL_STAMP_AT(56 + ((b0 - b_begin) >> 6));   // query chunk parked
-        TL_STAMP_AT(64 + ((b0 - b_begin) >> 6));   // label bits set
-        if (b0 + BC64 < b_end) fetch_chunk(b0 + BC64);
-        TL_STAMP_AT(72 + ((b0 - b_begin) >> 6));   // next chunk requested
         TL_STAMP();   // [0] staged, before the barrier
-        __syncthreads();
+        __syncthreads();   // REGC: this chunk's rows are parked (during the previous chunk) and the other buffer is free
         TL_STAMP();   // [1] start of score product
         {   // under the score product: the next chunk's label bits, the buffer after that cleared, one group of masked rows out
             const int pn = par == 2 ? 0 : par + 1, pc = pn == 2 ? 0 : pn + 1;
             if (tid < 2 * BC64) ybits3[pc * (2 * BC64) + tid] = 0u;
             if (b0 + BC64 < b_end) set_label_bits(b0 + BC64, ybits3 + pn * (2 * BC64));
-            if (b0 > b_begin && cm_done < NOIT) write_cm(cm_done++);
+            if (!REGC && b0 > b_begin && cm_done < NOIT) write_cm(cm_done++);
         }
 
         // ---- score blocks (rows 32h + 16rg + 4s + i, columns 16blk + c), rg = 0, 1 -----------------------------------
         v4f x0 = (v4f){0.f, 0.f, 0.f, 0.f}, x1 = (v4f){0.f, 0.f, 0.f, 0.f};
         {
-            const float *qa0 = Qs + (32 * h + c) * LDK + 4 * s;
+            const float *qa0 = Qc + (32 * h + c) * LDK + 4 * s;
             const float *qa1 = qa0 + 16 * LDK;
             const float *cb = Cs + (16 * blk + c) * LDK + 4 * s;
+            constexpr int NRD = REGC ? 2 : 3;                    // ds_reads per round
             v4f a00 = *reinterpret_cast<const v4f *>(qa0), a01 = *reinterpret_cast<const v4f *>(qa1);
-            v4f b0v = *reinterpret_cast<const v4f *>(cb);
+            v4f b0v = REGC ? breg[0] : *reinterpret_cast<const v4f *>(cb);
             v4f a10 = a00, a11 = a01, b1v = b0v;
             if (KB > 1) {
                 a10 = *reinterpret_cast<const v4f *>(qa0 + 16);
                 a11 = *reinterpret_cast<const v4f *>(qa1 + 16);
-                b1v = *reinterpret_cast<const v4f *>(cb + 16);
+                b1v = REGC ? breg[1] : *reinterpret_cast<const v4f *>(cb + 16);
             }
-            __builtin_amdgcn_sched_group_barrier(0x100, KB > 1 ? 6 : 3, 0);   // rounds 0 and 1 operands
+            __builtin_amdgcn_sched_group_barrier(0x100, KB > 1 ? 2 * NRD : NRD, 0);   // rounds 0 and 1 operands
 #pragma unroll
             for (int r = 0; r < KB; ++r) {
                 v4f a20 = a10, a21 = a11, b2v = b1v;
                 if (r + 2 < KB) {
                     a20 = *reinterpret_cast<const v4f *>(qa0 + 16 * (r + 2));
                     a21 = *reinterpret_cast<const v4f *>(qa1 + 16 * (r + 2));
-                    b2v = *reinterpret_cast<const v4f *>(cb + 16 * (r + 2));
+                    b2v = REGC ? breg[r + 2 < KB ? r + 2 : 0] : *reinterpret_cast<const v4f *>(cb + 16 * (r + 2));
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -270,14 +299,14 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
                 }
                 a00 = a10; a01 = a11; b0v = b1v;
                 a10 = a20; a11 = a21; b1v = b2v;
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 ds_read (round r+2)
+                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0); // ds_reads of round r+2
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA   (round r)
             }
         }
 
         TL_STAMP();   // [2] end of score product
         // B operands (query rows) of the dC product's first step: requested now, consumed after the epilogue
-        const float *qb = Qs + (32 * h + 4 * s) * LDK;
+        const float *qb = Qc + (32 * h + 4 * s) * LDK;
         v4f pb[KQ > 0 ? KQ : 1];
         float pr[KR > 0 ? KR : 1];
 #pragma unroll
@@ -329,6 +358,16 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
                 }
             }
         }
+        if (REGC && b0 + BC64 < b_end) {
+            // park the next chunk in the other buffer (its last readers finished before this chunk's barrier) and request the
+            // chunk after it: by now the waves of a SIMD are a phase apart, so this runs beside the other wave's MFMAs
+#pragma unroll
+            for (int it = 0; it < NQIT; ++it) {
+                const int q = q8 + QG * it;
+                if (q < NQ) *reinterpret_cast<v4f *>(Qn + r8 * LDK + 4 * q) = qreg[it];
+            }
+            if (b0 + 2 * BC64 < b_end) fetch_chunk(b0 + 2 * BC64);
+        }
         if (!a.loss_only) {
             // ---- G blocks -> HBM for dq_kernel: Gt[T][J][n_local][b_local], 4 consecutive batch rows per lane ------
             {
@@ -369,7 +408,7 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
             }
         }
         TL_STAMP();   // [3] end of dC product
-        __syncthreads();
+        if (!REGC || b0 + BC64 >= b_end) __syncthreads();   // (REGC: the next chunk's opening barrier is the only one it needs)
     }
     TL_STAMP();       // loop done
 
@@ -495,7 +534,9 @@ static size_t shmem64()
 template <int KB, int MODE>
 static hipError_t launch64_t(const FusedArgs &a, dim3 grid, hipStream_t st)
 {
-    auto k = fused_tile64_kernel<KB, MODE>;
+    // candidate operand in registers + two query chunk buffers: 4 KB more registers per lane, so slot sizes up to 208
+    static const bool regc_on = [] { const char *e = getenv("OKGE_TILE64_REGC"); return !e || atoi(e) != 0; }();
+    auto k = KB <= 13 && regc_on ? fused_tile64_kernel<KB, MODE, (KB <= 13)> : fused_tile64_kernel<KB, MODE, false>;
     const size_t shmem = shmem64<KB>();
     static bool configured = false;
     if (!configured) {
