@@ -26,6 +26,9 @@
 //     (e = 0..3).  Rows 16 apart start 16*LDK*4 bytes = a multiple of 256 B apart, so the four slots of a
 //     ds_read_b128 lane group hit 16 distinct 16-byte LDS slots (conflict-free).  Leftover 16-column blocks
 //     (KB mod 4) use ds_read_b32 with natural columns.
+#include <algorithm>
+#include <cstdlib>
+
 #include "okge_device.h"
 #include "okge_kernels.h"
 
@@ -516,7 +519,10 @@ __global__ __launch_bounds__(DqCfg<KB>::THREADS) void dq_kernel(const DqArgs a)
 // the chunks -- at two waves per SIMD like the two co-resident 4-wave workgroups before.  Wave (wq = w & 3, kh = w >> 2):
 // batch rows 16wq.., contraction steps 8kh .. 8kh+7 of every slot (candidates 16s + 8kh + t: slots stay 16 rows apart, the
 // B operand reads keep their conflict-free bank pattern); the two halves are added through LDS before the slab store.
-template <int KB>
+// DB (slot sizes up to 208: two tile pairs fit the LDS): chunk ch+1 is parked in the second pair while chunk ch is being
+// multiplied -- ONE barrier per chunk and no staging phase in which all eight waves write LDS and request the next chunk
+// while the MFMA pipes idle.  The two waves of a SIMD take turns: group kh = 0 parks before its MFMAs, group kh = 1 after.
+template <int KB, bool DB>
 __global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -524,6 +530,7 @@ __global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
     constexpr int NTHR = 512, QG = 16;                // staging: 16 column groups per row, 32 rows per pass
     constexpr int KQ = KB / 4, KR = KB % 4;
     constexpr int NO = 2 * KB, NOIT = (NO + QG - 1) / QG;
+    constexpr int PAIR = NT * LDK + NT * LDGT;        // floats of one (candidate tile, G^T tile) pair
     float *Cs = reinterpret_cast<float *>(smem);      // [NT][LDK]   masked candidate rows (end: the kh = 1 partial sums)
     float *Gt = Cs + NT * LDK;                        // [NT (n)][LDGT] : G^T tile, 64 batch rows wide
 
@@ -558,12 +565,13 @@ __global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
             }
         }
     };
-    if (ch_lo < ch_hi) prefetch(ch_lo);
-    for (int ch = ch_lo; ch < ch_hi; ++ch) {
+    // registers -> the LDS pair `buf` (0 / 1)
+    auto park = [&](int buf) {
+        float *cs = Cs + buf * PAIR, *gt = Gt + buf * PAIR;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int f = tid + it * NTHR;
-            *reinterpret_cast<v4f *>(Gt + (f >> 4) * LDGT + 4 * (f & 15)) = gv[it];
+            *reinterpret_cast<v4f *>(gt + (f >> 4) * LDGT + 4 * (f & 15)) = gv[it];
         }
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -572,17 +580,47 @@ __global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
             for (int it = 0; it < NOIT; ++it) {
                 const int o = tid % QG + QG * it;
                 if (o < NO) {
-                    *reinterpret_cast<v4f *>(Cs + r * LDK + 8 * o) = cv[(2 * pass) * NOIT + it];
-                    *reinterpret_cast<v4f *>(Cs + r * LDK + 8 * o + 4) = cv[(2 * pass + 1) * NOIT + it];
+                    *reinterpret_cast<v4f *>(cs + r * LDK + 8 * o) = cv[(2 * pass) * NOIT + it];
+                    *reinterpret_cast<v4f *>(cs + r * LDK + 8 * o + 4) = cv[(2 * pass + 1) * NOIT + it];
                 }
             }
         }
-        __syncthreads();
-        if (ch + 1 < ch_hi) prefetch(ch + 1);
-        // A[i = b][slot s, step t] = G^T[n = 16s + t][b = 16wq + c] ; B[slot][k] = C[n = 16s + t][k]
-        if (kh == 0) grad_product<KB, false, LDK, 0, 8>(acc, Gt + 16 * s * LDGT + 16 * wq + c, LDGT, Cs + 16 * s * LDK, c);
-        else         grad_product<KB, false, LDK, 8, 16>(acc, Gt + 16 * s * LDGT + 16 * wq + c, LDGT, Cs + 16 * s * LDK, c);
-        __syncthreads();
+    };
+    // A[i = b][slot s, step t] = G^T[n = 16s + t][b = 16wq + c] ; B[slot][k] = C[n = 16s + t][k]
+    auto product = [&](int buf) {
+        const float *cs = Cs + buf * PAIR, *gt = Gt + buf * PAIR;
+        if (kh == 0) grad_product<KB, false, LDK, 0, 8>(acc, gt + 16 * s * LDGT + 16 * wq + c, LDGT, cs + 16 * s * LDK, c);
+        else         grad_product<KB, false, LDK, 8, 16>(acc, gt + 16 * s * LDGT + 16 * wq + c, LDGT, cs + 16 * s * LDK, c);
+    };
+    if (ch_lo < ch_hi) prefetch(ch_lo);
+    if (DB) {
+        if (ch_lo < ch_hi) {
+            park(0);
+            if (ch_lo + 1 < ch_hi) prefetch(ch_lo + 1);
+        }
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            const int buf = (ch - ch_lo) & 1;
+            __syncthreads();                       // chunk ch is parked; the other pair's readers (chunk ch - 1) are done
+            const bool more = ch + 1 < ch_hi;
+            if (kh == 0 && more) {                 // this wave group parks its share of chunk ch + 1 first ...
+                park(buf ^ 1);
+                if (ch + 2 < ch_hi) prefetch(ch + 2);
+            }
+            product(buf);
+            if (kh == 1 && more) {                 // ... the other one after its MFMAs: a SIMD's two waves take turns
+                park(buf ^ 1);
+                if (ch + 2 < ch_hi) prefetch(ch + 2);
+            }
+        }
+        __syncthreads();                           // the pairs are free: pair 0's candidate tile takes the kh = 1 partial sums
+    } else {
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            park(0);
+            __syncthreads();
+            if (ch + 1 < ch_hi) prefetch(ch + 1);
+            product(0);
+            __syncthreads();
+        }
     }
     // the two contraction halves: kh = 1 parks its partial rows in LDS, kh = 0 adds them and stores the slab rows
     if (kh == 1) {
@@ -686,7 +724,12 @@ static hipError_t launch_dq_t(const DqArgs &a, int grid_x, size_t shmem, hipStre
 template <int KB>
 static hipError_t launch_dq8_t(const DqArgs &a, int grid_x, size_t shmem, hipStream_t st)
 {
-    auto k = dq8_kernel<KB>;
+    // two LDS tile pairs (slot sizes up to 208); OKGE_DQ8_DB=0: the single-pair loop
+    static const bool db_on = [] { const char *e = getenv("OKGE_DQ8_DB"); return !e || atoi(e) != 0; }();
+    constexpr bool CAN_DB = KB <= 13;
+    const bool db = CAN_DB && db_on;
+    auto k = db ? dq8_kernel<KB, CAN_DB> : dq8_kernel<KB, false>;
+    if (db) shmem *= 2;
     static size_t configured = 0;
     if (shmem > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
