@@ -321,6 +321,10 @@ def main():
             if name == "fused":
                 ev.update({"ms_per_batch": 1e3 * el / n_it, "prefixes_per_s": w.B * n_it / el, "groups": n_groups // n_it,
                            "mrr": res["mrr"].avg, "path": "okge_evaluate_fused_batches", "batches": n_it})
+                t0 = time.perf_counter()                 # steady state: start-up and the final host read amortised
+                ev_run.run([cb] * 640)
+                torch.cuda.synchronize()
+                ev["steady_ms_per_batch"] = 1e3 * (time.perf_counter() - t0) / 640
             else:
                 ev.update({"pipelined_ms_per_batch": 1e3 * el / n_it, "pipelined_mrr": res["mrr"].avg})
 

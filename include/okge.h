@@ -403,16 +403,17 @@ int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_pr
                               const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
                               void *workspace, size_t workspace_bytes, void *stream);
 /* A RUN of evaluation batches in one host call: Trainer.evaluate's loop (trainer.py:363-369) over n_batches batches.
- * Batch i runs on `stream` (i even) or `stream2` (i odd; NULL or == stream: everything on one stream); each stream is an
- * independent chain with two launches per batch -- [points i] [sweep i] [ranks i + points i+2] [sweep i+2] ... (the ranks
- * + meters of a batch and the point scores of the chain's next batch are independent and share a launch) -- and NO
- * dependency on the other chain, so the device fills one chain's small latency-bound launches with the other chain's
- * sweep.  Two cross-stream waits per CALL (stream2 joins behind stream at the start, stream waits for stream2 at the
- * end); a wait per batch costs ~10 us of queue latency on this hardware, more than the small kernels themselves.
- * Batches rotate over four quarters of `workspace` (each >= the largest batch's okge_eval_workspace_bytes, rounded up to
- * 256 bytes); batch i writes its ranks at ranks + rank_offset[i] (the exclusive prefix sum of n_groups keeps them all;
- * four rotating scratch regions are enough when only acc[7] is wanted).  On return all work has been ISSUED, `stream`
- * is ordered behind `stream2`'s share, and nothing has been synchronised with the host. */
+ * Batch i runs on streams[i % n_streams] (1 to 4 different streams); each stream is an independent chain with two launches
+ * per batch -- [points i] [sweep i] [ranks i + points i+S] [sweep i+S] ... (the ranks + meters of a batch and the point
+ * scores of the chain's next batch are independent and share a launch) -- and NO dependency on the other chains, so the
+ * device fills one chain's small latency-bound launches, and the CUs a sweep's tile grid leaves empty, with the other
+ * chains' work.  Cross-stream waits happen once per CALL (the other streams join behind streams[0] at the start,
+ * streams[0] waits for them at the end); a wait per batch costs ~10 us of queue latency on this hardware, more than the
+ * small kernels themselves.  Batches rotate over 2 n_streams slots of `workspace` (each >= the largest batch's
+ * okge_eval_workspace_bytes, rounded up to 256 bytes); batch i writes its ranks at ranks + rank_offset[i] (the exclusive
+ * prefix sum of n_groups keeps them all; 2 n_streams rotating scratch regions are enough when only acc[7] is wanted).
+ * On return all work has been ISSUED, streams[0] is ordered behind the other streams' share, and nothing has been
+ * synchronised with the host. */
 typedef struct okge_eval_batch {
     okge_prefix_batch batch;
     okge_candidates   cand;
@@ -426,7 +427,7 @@ typedef struct okge_eval_batch {
     int64_t           rank_offset; /* first element of this batch's ranks in ranks[] */
 } okge_eval_batch;
 int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *batches, int32_t n_batches, int64_t *ranks,
-                                double *acc, void *workspace, size_t workspace_bytes, void *stream, void *stream2);
+                                double *acc, void *workspace, size_t workspace_bytes, void *const *streams, int32_t n_streams);
 /* The same rank rule with the candidate columns [col0, col0 + n_local) of every row held by this rank
  * (scores: B x n_local; filter columns and group ids stay positions in the FULL candidate list):
  * true_out[g] = max over the group's ids inside the local range (-inf if none)       -> all-reduce(max)

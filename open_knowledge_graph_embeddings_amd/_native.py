@@ -228,7 +228,7 @@ def lib():
     L.okge_evaluate_fused_phase.argtypes = [c_int32] + L.okge_evaluate_fused.argtypes
     L.okge_evaluate_fused_batches.restype = c_int32
     L.okge_evaluate_fused_batches.argtypes = [POINTER(Tables), POINTER(EvalBatch), c_int32, c_void_p, c_void_p, c_void_p,
-                                              c_size_t, c_void_p, c_void_p]
+                                              c_size_t, POINTER(c_void_p), c_int32]
     L.okge_eval_workspace_bytes.restype = c_size_t
     L.okge_eval_workspace_bytes.argtypes = [c_int32, c_int32, c_int32, c_int64, c_int64]
     L.okge_pool_workspace_bytes.restype = c_size_t

@@ -1031,13 +1031,14 @@ int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_pr
                                workspace, workspace_bytes, stream);
 }
 
-// events of okge_evaluate_fused_batches (fork / join of the second stream), created once per process
+// events of okge_evaluate_fused_batches (fork / join of the extra streams), created once per process
+constexpr int EVAL_MAX_STREAMS = 4;
 static hipError_t eval_events(hipEvent_t **out)
 {
-    static hipEvent_t ev[2];
+    static hipEvent_t ev[EVAL_MAX_STREAMS];
     static bool ready = false;
     if (!ready) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < EVAL_MAX_STREAMS; ++i) {
             hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
             if (e != hipSuccess) return e;
         }
@@ -1048,13 +1049,19 @@ static hipError_t eval_events(hipEvent_t **out)
 }
 
 int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *batches, int32_t n_batches, int64_t *ranks,
-                                double *acc, void *workspace, size_t workspace_bytes, void *stream, void *stream2)
+                                double *acc, void *workspace, size_t workspace_bytes, void *const *streams, int32_t n_streams)
 {
-    if (!batches || n_batches < 0 || !ranks || !acc || !workspace) return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
+    if (!batches || n_batches < 0 || !ranks || !acc || !workspace || !streams || n_streams < 1 || n_streams > EVAL_MAX_STREAMS)
+        return fail(OKGE_ERR_INVALID, "bad evaluate arguments (1 to 4 streams)");
     if (n_batches == 0) return OKGE_OK;
-    hipStream_t st[2] = {reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipStream_t>(stream2 ? stream2 : stream)};
-    const bool two = st[0] != st[1];
-    const size_t quarter = (workspace_bytes / 4) & ~(size_t)255;
+    hipStream_t st[EVAL_MAX_STREAMS];
+    for (int i = 0; i < n_streams; ++i) {
+        st[i] = reinterpret_cast<hipStream_t>(streams[i]);
+        for (int j = 0; j < i; ++j)
+            if (st[j] == st[i]) return fail(OKGE_ERR_INVALID, "okge_evaluate_fused_batches: the streams must differ");
+    }
+    const int S = n_streams, slots = 2 * S;
+    const size_t slot_bytes = (workspace_bytes / slots) & ~(size_t)255;
     char *ws = static_cast<char *>(workspace);
     // everything that can be refused is refused before the first launch; batches without answer groups have nothing to
     // launch and drop out of the run
@@ -1065,42 +1072,43 @@ int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *bat
         if (b.rank_offset < 0) return fail(OKGE_ERR_INVALID, "negative rank_offset");
         EvalCall c;
         if (int rc = eval_call(c, t, &b.batch, &b.cand, b.filt_ptr, b.filt_col, b.n_filter, b.row_ptr, b.grp_ptr, b.ids, b.n_groups,
-                               ranks + b.rank_offset, acc, ws + (calls.size() & 3) * quarter, quarter))
+                               ranks + b.rank_offset, acc, ws + (calls.size() % slots) * slot_bytes, slot_bytes))
             return rc;
         if (c.n_groups > 0) calls.push_back(c);
     }
     const int n = (int)calls.size();
     if (n == 0) return OKGE_OK;
-    // Batch i runs on stream i & 1; each stream is an independent chain [points i] [sweep i] [ranks i + points i+2]
-    // [sweep i+2] ... with no dependency on the other, so the device fills one chain's small latency-bound launches with
-    // the other chain's sweep.  Four workspace slots: two batches in flight per chain.
+    // Batch i runs on stream i % S; each stream is an independent chain [points i] [sweep i] [ranks i + points i+S]
+    // [sweep i+S] ... with no dependency on the others, so the device fills one chain's small latency-bound launches (and
+    // the CUs a sweep's tile grid leaves empty) with the other chains' work.  2 S workspace slots: two batches in flight
+    // per chain.
     hipEvent_t *ev = nullptr;
     hipError_t e = hipSuccess;
 #define OKGE_EV(call, what) do { e = (call); if (e != hipSuccess) return fail_hip(e, what); } while (0)
-    if (two) {
+    if (S > 1) {
         OKGE_EV(eval_events(&ev), "create evaluation events");
-        OKGE_EV(hipEventRecord(ev[0], st[0]), "record fork");          // the second stream joins behind whatever produced
-        OKGE_EV(hipStreamWaitEvent(st[1], ev[0], 0), "fork");          // the tables / batches on the first
+        OKGE_EV(hipEventRecord(ev[0], st[0]), "record fork");          // the other streams join behind whatever produced
+        for (int k = 1; k < S; ++k) OKGE_EV(hipStreamWaitEvent(st[k], ev[0], 0), "fork");   // the tables / batches on the first
     }
     auto clear_counts = [&](const EvalCall &c, hipStream_t s) {      // (atomics path of very large batches only)
         return c.eg.slab ? hipSuccess : hipMemsetAsync(c.counts, 0, (size_t)c.n_groups * 2 * sizeof(int32_t), s);
     };
     for (int i = 0; i < n; ++i) {
-        hipStream_t s = st[i & 1];
-        if (i < 2) {                                                   // head of a chain
+        hipStream_t s = st[i % S];
+        if (i < S) {                                                   // head of a chain
             OKGE_EV(clear_counts(calls[i], s), "clear rank counters");
             ScopedTimer tm("eval_points", s);
             OKGE_EV(launch_eval_side(&calls[i].pts, nullptr, s), "eval_points");
         }
         if (int rc = eval_issue(2, calls[i], s)) return rc;
-        const EvalCall *nx = i + 2 < n ? &calls[i + 2] : nullptr;      // the chain's next batch
+        const EvalCall *nx = i + S < n ? &calls[i + S] : nullptr;      // the chain's next batch
         if (nx) OKGE_EV(clear_counts(*nx, s), "clear rank counters");
         ScopedTimer tm("eval_ranks+points", s);
         OKGE_EV(launch_eval_side(nx ? &nx->pts : nullptr, &calls[i].rk, s), "eval_side");
     }
-    if (two) {
-        OKGE_EV(hipEventRecord(ev[1], st[1]), "record join");
-        OKGE_EV(hipStreamWaitEvent(st[0], ev[1], 0), "join");
+    for (int k = 1; k < S; ++k) {
+        OKGE_EV(hipEventRecord(ev[k], st[k]), "record join");
+        OKGE_EV(hipStreamWaitEvent(st[0], ev[k], 0), "join");
     }
 #undef OKGE_EV
     return OKGE_OK;

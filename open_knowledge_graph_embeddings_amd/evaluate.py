@@ -26,19 +26,23 @@ def _meters(a):
 
 class FusedEvaluator:
     """The evaluation loop on okge_evaluate_fused_batches: no (B, N) score block, no host read until the end.  The library
-    issues a run of batches per call (`run_len`; the first runs are short so that the device starts early): even batches
-    on the current stream, odd ones on a second stream, each stream an independent chain of two launches per batch -- the
-    tile sweep with in-register counting, then one small launch holding the ranks + meters of that batch and the point
-    scores of the chain's next batch -- so one chain's small latency-bound launches run beside the other chain's sweep
-    without any per-batch cross-stream wait (those cost ~10 us each; round 2's first design paid one per batch).
+    issues a run of batches per call (`run_len`; the first runs are short so that the device starts early): batch i on
+    stream i % n_streams (the current stream + n_streams - 1 of its own; default 3), each stream an independent chain of
+    two launches per batch -- the tile sweep with in-register counting, then one small launch holding the ranks + meters
+    of that batch and the point scores of the chain's next batch -- so one chain's small latency-bound launches, and the
+    CUs a sweep's 228 tiles leave empty, are filled with the other chains' work without any per-batch cross-stream wait
+    (those cost ~10 us each; round 2's first design paid one per batch).  Measured per batch at the FB15k-237 shape:
+    1 chain 0.056 ms, 2 chains 0.046, 3 chains 0.043, 4 chains 0.043-0.048.
     Slot sizes up to 256, eval mode; PipelinedEvaluator (materialised scores) covers the rest."""
 
-    def __init__(self, E, R, scorer, engine=None, run_len=32, two_streams=True):
+    def __init__(self, E, R, scorer, engine=None, run_len=48, two_streams=True, n_streams=None):
         self.E, self.R, self.scorer = E, R, scorer
         self.device = E.device
         self.engine = engine or H.HotPath(self.device)
         self.run_len = int(run_len)
-        self.side = torch.cuda.Stream(device=self.device) if two_streams else None
+        self.n_streams = int(n_streams) if n_streams is not None else (3 if two_streams else 1)
+        self.sides = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams - 1)]
+        self.side = self.sides[0] if self.sides else None
         self._ws = None
         self._ranks = None
         self._t = self.engine._tables(E, R, scorer)
@@ -56,27 +60,28 @@ class FusedEvaluator:
         return need, n_groups, keep
 
     def _issue(self, n, need, n_groups, acc, stream_h):
-        quarter = (need + 255) // 256 * 256
-        if self._ws is None or self._ws.numel() < 4 * quarter or self._ranks.numel() < 4 * n_groups:
-            self._ws = torch.empty(4 * max(quarter, 0 if self._ws is None else self._ws.numel() // 4), dtype=torch.uint8,
+        slots = 2 * self.n_streams
+        slot = (need + 255) // 256 * 256
+        if self._ws is None or self._ws.numel() < slots * slot or self._ranks.numel() < slots * n_groups:
+            self._ws = torch.empty(slots * max(slot, 0 if self._ws is None else self._ws.numel() // slots), dtype=torch.uint8,
                                    device=self.device)
-            self._ranks = torch.empty(max(4 * n_groups, 4096, 0 if self._ranks is None else self._ranks.numel()),
+            self._ranks = torch.empty(max(slots * n_groups, 4096, 0 if self._ranks is None else self._ranks.numel()),
                                       dtype=torch.int64, device=self.device)
-        for i in range(n):                                   # the ranks themselves are scratch here: four regions rotate
-            self._arr[i].rank_offset = (i & 3) * n_groups
-        side_h = ctypes.c_void_p(self.side.cuda_stream) if self.side is not None else None
-        # (the library orders the current stream behind the second stream's share at the end of every call; letting the
+        for i in range(n):                                   # the ranks themselves are scratch here: the regions rotate
+            self._arr[i].rank_offset = (i % slots) * n_groups
+        handles = (ctypes.c_void_p * self.n_streams)(stream_h, *[ctypes.c_void_p(x.cuda_stream) for x in self.sides])
+        # (the library orders the current stream behind the other streams' share at the end of every call; letting the
         #  chains run on across calls instead measured no faster)
         N.check(self.engine.lib.okge_evaluate_fused_batches(ctypes.byref(self._t), self._arr, n, self._ranks.data_ptr(),
-                                                            acc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), stream_h,
-                                                            side_h), "okge_evaluate_fused_batches")
+                                                            acc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), handles,
+                                                            self.n_streams), "okge_evaluate_fused_batches")
 
     def run(self, batches):
         """batches: iterable of dataset.CollatedBatch built with is_training_data=False -> (MetricResult, #groups)"""
         acc = torch.zeros(7, dtype=torch.float64, device=self.device)
         main = torch.cuda.current_stream(self.device)
         stream_h = ctypes.c_void_p(main.cuda_stream)
-        n, need, n_groups, run = 0, 0, 0, min(2, self.run_len)
+        n, need, n_groups, run = 0, 0, 0, min(max(2, self.n_streams), self.run_len)
         keep = []                       # a run's tensors (and id conversions) stay referenced until it has been issued:
         for cb in batches:              # after that the current stream's order protects them (see _issue)
             nd, ng, ka = self._fill(n, cb)

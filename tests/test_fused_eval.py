@@ -177,23 +177,27 @@ def test_fused_batches_ranks_equal_single_calls(okge_lib):
         need = max(need, nd)
         fe._arr[i].rank_offset = off
         off += ng
-    quarter = (need + 255) // 256 * 256
-    ws = torch.empty(4 * quarter, dtype=torch.uint8, device=Et.device)
+    slot = (need + 255) // 256 * 256
+    ws = torch.empty(6 * slot, dtype=torch.uint8, device=Et.device)
     ranks = torch.full((off,), -7, dtype=torch.int64, device=Et.device)
     acc = torch.zeros(7, dtype=torch.float64, device=Et.device)
-    main = ctypes.c_void_p(torch.cuda.current_stream(Et.device).cuda_stream)
+    main = torch.cuda.current_stream(Et.device).cuda_stream
+    extra = [torch.cuda.Stream(device=Et.device) for _ in range(2)]
     args = (ctypes.byref(fe._t), fe._arr, len(cbs), ranks.data_ptr(), acc.data_ptr(), ws.data_ptr())
-    for second in (None, ctypes.c_void_p(fe.side.cuda_stream)):          # one stream; two independent chains
+    def streams(k):
+        return (ctypes.c_void_p * k)(main, *[x.cuda_stream for x in extra[:k - 1]]), k
+    for k in (1, 2, 3):                                                  # one stream; two / three independent chains
         ranks.fill_(-7)
         acc.zero_()
         torch.cuda.synchronize()
-        NV.check(hp.lib.okge_evaluate_fused_batches(*args, ws.numel(), main, second), "okge_evaluate_fused_batches")
+        NV.check(hp.lib.okge_evaluate_fused_batches(*args, ws.numel(), *streams(k)), "okge_evaluate_fused_batches")
         torch.cuda.synchronize()
         assert np.array_equal(ranks.cpu().numpy(), np.concatenate(want))
         assert int(acc[0].item()) == off
     # too small a workspace: refused before the first launch, nothing written
     ranks.fill_(-7)
-    assert hp.lib.okge_evaluate_fused_batches(*args, 3 * quarter, main, None) != 0
+    assert hp.lib.okge_evaluate_fused_batches(*args, 3 * slot, *streams(2)) != 0
+    assert hp.lib.okge_evaluate_fused_batches(*args, ws.numel(), (ctypes.c_void_p * 2)(main, main), 2) != 0    # the same stream twice
     torch.cuda.synchronize()
     assert int((ranks != -7).sum().item()) == 0
 
