@@ -312,7 +312,8 @@ def main():
         # pipelined: the materialising path (scores on one stream, ranks + meters on another), kept for d > 256 / dropout
         for name, cls in (("fused", FusedEvaluator), ("pipelined", PipelinedEvaluator)):
             ev_run = cls(Et, Rt, w.scorer, engine=step.engine)
-            ev_run.run([cb] * 64)       # warm-up (a fresh side stream's first ~50 launches are slow: runtime-side pools)
+            ev_run.run([cb] * 192)      # warm-up: fresh streams are slow until the runtime's per-queue pools have grown to the
+                                        # depth a full run of batches keeps in flight (first 640-batch pass: 0.11 ms per batch)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             res, n_groups = ev_run.run([cb] * n_it)

@@ -34,7 +34,7 @@ for name, cls in (("fused", FusedEvaluator), ("fused-one-group", FusedEvaluator)
     elif name == "pipelined":
         cb = cb_keep
     ev = cls(Et, Rt, w.scorer, engine=eng)
-    ev.run([cb] * 64)           # a fresh side stream's first ~50 launches are slow (runtime-side pools): warm them
+    ev.run([cb] * 192)          # fresh streams are slow until the runtime's per-queue pools have grown to a full run's depth
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev.run([cb] * 40)
