@@ -309,7 +309,8 @@ def main():
         n_it = 70                        # one validation pass at the FB15k-237 shape: 2 x 17 535 prefixes / 512
         ev = {}
         # fused: point scores + tile sweep counting in registers + ranks/meters, no (B, N) score block (okge_evaluate_fused);
-        # pipelined: the materialising path (scores on one stream, ranks + meters on another), kept for d > 256 / dropout
+        # pipelined: the materialising path (scores, ranks, meters per batch; independent chains on three streams): any
+        # slot size, dropout
         for name, cls in (("fused", FusedEvaluator), ("pipelined", PipelinedEvaluator)):
             ev_run = cls(Et, Rt, w.scorer, engine=step.engine)
             ev_run.run([cb] * 192)      # warm-up: fresh streams are slow until the runtime's per-queue pools have grown to the
@@ -328,6 +329,10 @@ def main():
                 ev["steady_ms_per_batch"] = 1e3 * (time.perf_counter() - t0) / 640
             else:
                 ev.update({"pipelined_ms_per_batch": 1e3 * el / n_it, "pipelined_mrr": res["mrr"].avg})
+                t0 = time.perf_counter()
+                ev_run.run([cb] * 640)
+                torch.cuda.synchronize()
+                ev["pipelined_steady_ms_per_batch"] = 1e3 * (time.perf_counter() - t0) / 640
 
     # ---- the north-star's second shape: S-OLP (|E| = 2.5 M, |R| = 100 k, d = 256, B = 4096, Zipf(1.1) prefix entities),
     #      the SAME global problem at every N (strong scaling), entity table row-sharded over the ranks; a handful of steps

@@ -99,31 +99,36 @@ class FusedEvaluator:
 
 
 class PipelinedEvaluator:
-    def __init__(self, E, R, scorer, engine=None):
+    """The evaluation loop on the MATERIALISING path (okge_evaluate_batch: scores into a (B, N) block, then filtered ranks
+    and meters) -- any slot size, dropout, candidate tables; FusedEvaluator is the fast path for slot sizes up to 256 in
+    eval mode.  Batch i runs on stream i % n_streams with that stream's own score block, rank buffer and query workspace:
+    independent chains [scores] [ranks] [meters], no cross-stream wait per batch (each costs ~10 us of queue latency on
+    this hardware; the first version ordered a scoring and a ranking stream with two events per batch), so the ranking of
+    one batch runs beside the scoring of the next ones.  Meters accumulate on the device; one host read at the end."""
+
+    def __init__(self, E, R, scorer, engine=None, n_streams=3):
         self.E, self.R, self.scorer = E, R, scorer
         self.device = E.device
         self.engine = engine or H.HotPath(self.device)
-        self.rank_stream = torch.cuda.Stream(device=self.device)
-        self._bufs = [None, None]
-        self._ranks = [None, None]
-        # the descriptors of a call are built once and only their per-batch pointers change: at ~60 us of device work
-        # per batch the Python cost of filling three ctypes structs is what decides whether the two streams overlap
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n_streams)))]
+        k = len(self.streams)
+        self._bufs, self._ranks, self._ws = [None] * k, [None] * k, [None] * k
+        # the descriptors of a call are built once and only their per-batch pointers change
         self._t = self.engine._tables(E, R, scorer)
         self._pb, self._c = N.PrefixBatch(), N.Candidates()
-        self._rs = ctypes.c_void_p(self.rank_stream.cuda_stream)
 
     def _buffer(self, slot, B, n):
-        """score buffer of a slot: grown (never shrunk) to the largest B x ld seen, and only after the rank stream has
-        drained -- the ranks kernel of an earlier batch may still be reading the old one -- so a slot keeps ONE
-        pointer for the library's per-buffer events; the rank stream is recorded as a user of the allocation"""
+        """score block of a chain: grown (never shrunk) to the largest B x ld seen.  Allocated and freed on the caller's
+        stream; every chain joins that stream at the start and at the end of run(), and inside a run a chain's buffer
+        changes only between two of ITS OWN batches, i.e. in its own stream's order, after a synchronize."""
         ld = (n + 3) // 4 * 4
         buf = self._bufs[slot]
         if buf is None or buf.shape[0] < B or buf.shape[1] < ld:
-            self.rank_stream.synchronize()
+            self.streams[slot].synchronize()
             rows = max(B, 0 if buf is None else buf.shape[0])
             cols = max(ld, 0 if buf is None else buf.shape[1])
             buf = self._bufs[slot] = torch.empty((rows, cols), dtype=torch.float32, device=self.device)
-            buf.record_stream(self.rank_stream)
+            buf.record_stream(self.streams[slot])
         return buf[:B, :n]
 
     def run(self, batches):
@@ -132,33 +137,39 @@ class PipelinedEvaluator:
         eng = self.engine
         acc = torch.zeros(7, dtype=torch.float64, device=self.device)
         main = torch.cuda.current_stream(self.device)
-        keep = None
+        for st in self.streams:
+            st.wait_stream(main)                             # tables / batches were produced on the current stream
+        keep = []                                            # every batch stays referenced until the chains have joined
         for i, cb in enumerate(batches):
-            slot = i & 1
+            slot = i % len(self.streams)
+            st = self.streams[slot]
             x = self._buffer(slot, cb.batch.B, cb.n_cand)
             n_groups = int(cb.grp_ptr.numel()) - 1
             if self._ranks[slot] is None or self._ranks[slot].numel() < n_groups:
-                self.rank_stream.synchronize()
+                st.synchronize()
                 self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
-                self._ranks[slot].record_stream(self.rank_stream)
-            for t in (cb.filt_ptr, cb.filt_col, cb.row_ptr, cb.grp_ptr, cb.ids):
-                t.record_stream(self.rank_stream)                # read there after `cb` may have gone out of scope here
-            # one library call: scores on the current stream, ranks + meters on rank_stream, ordered by library events;
-            # the buffer of batch i-2 is reused only after its ranks were counted
+                self._ranks[slot].record_stream(st)
             b, pb, c = cb.batch, self._pb, self._c
             pb.po_rel, pb.po_obj = (b.po_rel.data_ptr(), b.po_obj.data_ptr()) if b.po_rel is not None else (None, None)
             pb.sp_subj, pb.sp_rel = (b.sp_subj.data_ptr(), b.sp_rel.data_ptr()) if b.sp_subj is not None else (None, None)
             pb.n_po, pb.n_sp = b.n_po, b.n_sp
             c.ids = b.cand_ids.data_ptr() if b.cand_ids is not None else None
             c.first_id, c.n = b.cand_first, cb.n_cand
-            ws = eng.workspace(b.B, cb.n_cand, self._t.d, "score")
+            need = int(eng.lib.okge_score_workspace_bytes(b.B, self._t.d))
+            if self._ws[slot] is None or self._ws[slot].numel() < need:
+                st.synchronize()
+                self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                self._ws[slot].record_stream(st)
+            sh = ctypes.c_void_p(st.cuda_stream)
+            # one library call: scores, ranks and meters of the batch, all in the chain's stream order
             N.check(eng.lib.okge_evaluate_batch(ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c),
                                                 cb.filt_ptr.data_ptr(), cb.filt_col.data_ptr() if cb.filt_col.numel() else None,
                                                 cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(), cb.ids.data_ptr(), n_groups,
                                                 x.data_ptr(), x.stride(0), self._ranks[slot].data_ptr(), acc.data_ptr(),
-                                                ws.data_ptr(), eng._ws_bytes, eng._stream(), self._rs), "okge_evaluate_batch")
-            keep = cb
-        main.wait_stream(self.rank_stream)
+                                                self._ws[slot].data_ptr(), self._ws[slot].numel(), sh, sh), "okge_evaluate_batch")
+            keep.append(cb)
+        for st in self.streams:
+            main.wait_stream(st)
         a = acc.cpu().tolist()
         del keep
         return _meters(a)
