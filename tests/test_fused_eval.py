@@ -227,3 +227,40 @@ def test_fused_run_with_empty_and_one_direction_batches(okge_lib):
         assert na == nb and na > 0
         for k in ("mrr", "mr", "h1", "h3", "h10", "h50"):
             assert abs(a[k].avg - b[k].avg) <= 1e-12 * max(1.0, abs(b[k].avg)), (two, k)
+
+
+def test_evaluator_chain_counts_agree(okge_lib):
+    """1 to 4 independent chains (FusedEvaluator) and 1 or 3 chains (PipelinedEvaluator) give the same meters; the C entry
+    refuses 0 and 5 streams"""
+    import ctypes
+    import torch
+    from open_knowledge_graph_embeddings_amd.dataset import CollatedBatch
+    from open_knowledge_graph_embeddings_amd.evaluate import FusedEvaluator, PipelinedEvaluator
+    rng = np.random.default_rng(31)
+    n_ent, d = 1100, 96
+    E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal((9, d)) * 0.3).astype(np.float32)
+    Et, Rt = _dev(E), _dev(R)
+    cbs = []
+    for k in range(11):
+        _, _, batch, csr, N = _case(rng, n_ent, 9, d, 13 + 5 * k, 37 - 3 * k, "complex", 2 + k % 2, False, cand_list=k == 7)
+        dd = {kk: _dev(v) for kk, v in csr.items()}
+        cbs.append(CollatedBatch(batch, 1.0, 1.0, N, row_ptr=dd["row_ptr"], grp_ptr=dd["grp_ptr"], ids=dd["ids"],
+                                 filt_ptr=dd["filt_ptr"], filt_col=dd["filt_col"]))
+    ref, n_ref = PipelinedEvaluator(Et, Rt, "complex", n_streams=1).run(cbs)
+    runs = [FusedEvaluator(Et, Rt, "complex", n_streams=k, run_len=5).run(cbs) for k in (1, 2, 3, 4)]
+    runs.append(PipelinedEvaluator(Et, Rt, "complex", n_streams=3).run(cbs))
+    for res, n in runs:
+        assert n == n_ref
+        for key in ("mrr", "mr", "h1", "h3", "h10", "h50"):
+            assert abs(res[key].avg - ref[key].avg) <= 1e-12 * max(1.0, abs(ref[key].avg)), key
+    fe = FusedEvaluator(Et, Rt, "complex", n_streams=1, run_len=2)
+    fe._fill(0, cbs[0])
+    fe._arr[0].rank_offset = 0
+    ws = torch.empty(1 << 22, dtype=torch.uint8, device=Et.device)
+    rk = torch.empty(4096, dtype=torch.int64, device=Et.device)
+    acc = torch.zeros(7, dtype=torch.float64, device=Et.device)
+    h = (ctypes.c_void_p * 5)(*[torch.cuda.current_stream(Et.device).cuda_stream] * 5)
+    for bad in (0, 5):
+        assert fe.engine.lib.okge_evaluate_fused_batches(ctypes.byref(fe._t), fe._arr, 1, rk.data_ptr(), acc.data_ptr(), ws.data_ptr(),
+                                                         ws.numel(), h, bad) != 0
