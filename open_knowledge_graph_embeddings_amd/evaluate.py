@@ -81,7 +81,7 @@ class FusedEvaluator:
         acc = torch.zeros(7, dtype=torch.float64, device=self.device)
         main = torch.cuda.current_stream(self.device)
         stream_h = ctypes.c_void_p(main.cuda_stream)
-        n, need, n_groups, run = 0, 0, 0, min(max(2, self.n_streams), self.run_len)
+        n, need, n_groups, run = 0, 0, 0, min(2 * self.n_streams, self.run_len)   # two batches per chain, then x4:
         keep = []                       # a run's tensors (and id conversions) stay referenced until it has been issued:
         for cb in batches:              # after that the current stream's order protects them (see _issue)
             nd, ng, ka = self._fill(n, cb)
@@ -90,7 +90,7 @@ class FusedEvaluator:
             if n == run:
                 self._issue(n, need, n_groups, acc, stream_h)
                 keep.clear()
-                n, need, n_groups, run = 0, 0, 0, min(2 * run, self.run_len)
+                n, need, n_groups, run = 0, 0, 0, min(4 * run, self.run_len)          # the host fills ~4 batches per batch time
         if n:
             self._issue(n, need, n_groups, acc, stream_h)
         out = _meters(acc.cpu().tolist())          # (synchronises: every kernel that read a batch has finished)
