@@ -239,6 +239,11 @@ CASES = [
     ("distmult", 2000, 30, 512, 70, 61, 700, "bce", 0.0),      # slot sizes above 256: the KB=32 instantiations
     ("complex", 900, 20, 320, 33, 40, None, "kl", 0.0),
     ("complex", 700, 11, 512, 40, 0, None, "bce", 0.1),
+    # few candidate tiles, many batch rows: the batch is split over blockIdx.y (partial dE slabs + dc_reduce) -- the shape of
+    # a multi-GPU shard -- on the register-operand tile kernel and the double-buffered dQ kernel (slot sizes up to 208)
+    ("complex", 1502, 20, 200, 256, 256, None, "bce", 0.0),
+    ("complex", 3000, 20, 200, 250, 200, 700, "kl", 0.0),
+    ("distmult", 1200, 15, 128, 300, 221, None, "bce", 0.1),
 ]
 
 
