@@ -241,19 +241,34 @@ def main():
         run = lambda i: graphs[i % N_BATCHES].replay()                      # noqa: E731
     for i in range(args.warmup):
         run(i)
-    barrier()
-    t0 = time.perf_counter()
-    triples = 0
-    for i in range(args.steps):
-        run(i)
-        triples += n_pos[i % N_BATCHES]
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    def timed_window():
+        """EXACTLY args.steps steps between two barrier + synchronize brackets; wall time = the slowest rank's"""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            run(i)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax[0].item())        # every rank processed the same global batches: count them once
+        return el
+
+    # A short window (the driver's --steps 20 is 2.8 ms of device time) is at the mercy of one clock ramp or one host
+    # hiccup, so the measurement is repeated: up to 9 windows of `steps` steps each (fewer when one window is long: about
+    # 20 s in total; the count follows from the rank-maximum time, so every rank runs the same number), and the line reports
+    # the MEDIAN window as ms_per_step / value, with the fastest and slowest beside it.
+    windows = [timed_window()]
+    n_windows = max(1, min(9, int(20.0 / max(windows[0], 1e-6))))
+    if n_windows > 1 and n_windows % 2 == 0:
+        n_windows -= 1
+    while len(windows) < n_windows:
+        windows.append(timed_window())
+    elapsed = float(np.median(windows))
+    triples = sum(n_pos[i % N_BATCHES] for i in range(args.steps))
     loss_last = float((step.reduce_loss() if sharded else step.loss_out).item())
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0].item())        # every rank processed the same global batches: count them once
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, separate pass ------------------
     roof = None
@@ -261,7 +276,7 @@ def main():
     eng = step.engine
     if rank == 0:
         eng.timing(True)
-    ksteps = min(args.steps, 50)
+    ksteps = max(50, min(args.steps, 200))       # (outside the timed windows: enough launches for a stable per-kernel average)
     for i in range(ksteps):
         run(i)
     barrier()
@@ -355,6 +370,8 @@ def main():
         "metric": "training triples/sec (1-vs-all ComplEx d=200)" if w.name.startswith("S-FB") and w.d == 200
                   else f"training triples/sec (1-vs-all {w.scorer} d={w.d})", "value": triples / elapsed, "unit": "triples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_min": 1e3 * min(windows) / args.steps, "ms_per_step_max": 1e3 * max(windows) / args.steps,
+        "timed_windows": len(windows),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{w.name}: {'FB15k-237' if w.name.startswith('S-FB') else 'OLPBENCH'}-shaped |E|={w.n_ent} |R|={w.n_rel} d={w.d} ComplEx 1-vs-all "
                                f"N={w.N}, B={w_run.B} ({w_run.n_po} po + {w_run.n_sp} sp), BCE, input_dropout "

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libokge_hip.so")
 SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_train64.hip", "okge_misc.hip", "okge_pool.hip", "okge_collate.cpp", "okge_dataset.cpp"]
-HEADERS = ["okge_device.h", "okge_kernels.h", os.path.join("..", "..", "include", "okge.h")]
+# every header a source may include: all of csrc/*.h (listed by the directory, so a new header cannot be forgotten) + the ABI
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "okge.h")]
 
 OKGE_COMPLEX, OKGE_DISTMULT = 0, 1
 OKGE_LOSS_BCE, OKGE_LOSS_KL = 0, 1

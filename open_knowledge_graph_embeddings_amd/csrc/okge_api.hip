@@ -78,15 +78,27 @@ struct ScopedTimer {
 };
 
 // ---- device word counting out-of-range ids (checked_row in the kernels); read and cleared by okge_id_errors ------------
-int *g_id_err = nullptr;
+// One word PER DEVICE (keyed by hipGetDevice() at the call): a process that drives several devices must never hand a kernel
+// on device b a pointer that lives on device a.
+constexpr int OKGE_MAX_DEVICES = 64;
+static std::mutex g_dev_mu;
+static int *g_id_err[OKGE_MAX_DEVICES] = {};
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OKGE_MAX_DEVICES) return -1;
+    return dev;
+}
 int *id_err_ptr()
 {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        if (hipMalloc(reinterpret_cast<void **>(&g_id_err), sizeof(int)) != hipSuccess) { g_id_err = nullptr; return; }
-        (void)hipMemset(g_id_err, 0, sizeof(int));
-    });
-    return g_id_err;
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (!g_id_err[dev]) {
+        if (hipMalloc(reinterpret_cast<void **>(&g_id_err[dev]), sizeof(int)) != hipSuccess) { g_id_err[dev] = nullptr; return nullptr; }
+        (void)hipMemset(g_id_err[dev], 0, sizeof(int));
+    }
+    return g_id_err[dev];
 }
 
 // ---- helpers ---------------------------------------------------------------------------------------------
@@ -1031,20 +1043,25 @@ int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_pr
                                workspace, workspace_bytes, stream);
 }
 
-// events of okge_evaluate_fused_batches (fork / join of the extra streams), created once per process
+// events of okge_evaluate_fused_batches (fork / join of the extra streams): one set per device, created on first use on that
+// device.  A set is only used between the fork and the join of ONE call, and calls on one device are issued by one host
+// thread at a time (the first stream orders them), so evaluators sharing a device can share the set.
 constexpr int EVAL_MAX_STREAMS = 4;
 static hipError_t eval_events(hipEvent_t **out)
 {
-    static hipEvent_t ev[EVAL_MAX_STREAMS];
-    static bool ready = false;
-    if (!ready) {
+    static hipEvent_t ev[OKGE_MAX_DEVICES][EVAL_MAX_STREAMS];
+    static bool ready[OKGE_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (!ready[dev]) {
         for (int i = 0; i < EVAL_MAX_STREAMS; ++i) {
-            hipError_t e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+            hipError_t e = hipEventCreateWithFlags(&ev[dev][i], hipEventDisableTiming);
             if (e != hipSuccess) return e;
         }
-        ready = true;
+        ready[dev] = true;
     }
-    *out = ev;
+    *out = ev[dev];
     return hipSuccess;
 }
 
@@ -1063,21 +1080,22 @@ int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *bat
     const int S = n_streams, slots = 2 * S;
     const size_t slot_bytes = (workspace_bytes / slots) & ~(size_t)255;
     char *ws = static_cast<char *>(workspace);
-    // everything that can be refused is refused before the first launch; batches without answer groups have nothing to
-    // launch and drop out of the run
-    std::vector<EvalCall> calls;
-    calls.reserve((size_t)n_batches);
+    // everything that can be refused is refused before the first launch.  Stream, workspace slot and position in the chain
+    // come from the batch's index IN THE CALL -- the caller numbers its rank regions by that index too --, so a batch without
+    // answer groups keeps its place and simply launches nothing (dropping it would shift the batches behind it onto other
+    // chains while their rank regions stay where the caller put them: two unordered chains writing one region).
+    std::vector<EvalCall> calls((size_t)n_batches);
+    int live = 0;
     for (int i = 0; i < n_batches; ++i) {
         const okge_eval_batch &b = batches[i];
         if (b.rank_offset < 0) return fail(OKGE_ERR_INVALID, "negative rank_offset");
-        EvalCall c;
-        if (int rc = eval_call(c, t, &b.batch, &b.cand, b.filt_ptr, b.filt_col, b.n_filter, b.row_ptr, b.grp_ptr, b.ids, b.n_groups,
-                               ranks + b.rank_offset, acc, ws + (calls.size() % slots) * slot_bytes, slot_bytes))
+        if (int rc = eval_call(calls[i], t, &b.batch, &b.cand, b.filt_ptr, b.filt_col, b.n_filter, b.row_ptr, b.grp_ptr, b.ids,
+                               b.n_groups, ranks + b.rank_offset, acc, ws + (size_t)(i % slots) * slot_bytes, slot_bytes))
             return rc;
-        if (c.n_groups > 0) calls.push_back(c);
+        live += calls[i].n_groups > 0;
     }
-    const int n = (int)calls.size();
-    if (n == 0) return OKGE_OK;
+    const int n = n_batches;
+    if (live == 0) return OKGE_OK;
     // Batch i runs on stream i % S; each stream is an independent chain [points i] [sweep i] [ranks i + points i+S]
     // [sweep i+S] ... with no dependency on the others, so the device fills one chain's small latency-bound launches (and
     // the CUs a sweep's tile grid leaves empty) with the other chains' work.  2 S workspace slots: two batches in flight
@@ -1095,16 +1113,19 @@ int okge_evaluate_fused_batches(const okge_tables *t, const okge_eval_batch *bat
     };
     for (int i = 0; i < n; ++i) {
         hipStream_t s = st[i % S];
-        if (i < S) {                                                   // head of a chain
+        const bool has = calls[i].n_groups > 0;
+        if (i < S && has) {                                            // head of a chain
             OKGE_EV(clear_counts(calls[i], s), "clear rank counters");
             ScopedTimer tm("eval_points", s);
             OKGE_EV(launch_eval_side(&calls[i].pts, nullptr, s), "eval_points");
         }
-        if (int rc = eval_issue(2, calls[i], s)) return rc;
-        const EvalCall *nx = i + S < n ? &calls[i + S] : nullptr;      // the chain's next batch
+        if (has)
+            if (int rc = eval_issue(2, calls[i], s)) return rc;
+        const EvalCall *nx = (i + S < n && calls[i + S].n_groups > 0) ? &calls[i + S] : nullptr;      // the chain's next batch
         if (nx) OKGE_EV(clear_counts(*nx, s), "clear rank counters");
+        if (!nx && !has) continue;
         ScopedTimer tm("eval_ranks+points", s);
-        OKGE_EV(launch_eval_side(nx ? &nx->pts : nullptr, &calls[i].rk, s), "eval_side");
+        OKGE_EV(launch_eval_side(nx ? &nx->pts : nullptr, has ? &calls[i].rk : nullptr, s), "eval_side");
     }
     for (int k = 1; k < S; ++k) {
         OKGE_EV(hipEventRecord(ev[k], st[k]), "record join");

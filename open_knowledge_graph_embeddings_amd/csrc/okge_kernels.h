@@ -2,10 +2,30 @@
 #pragma once
 #include <string>
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include "okge_device.h"
 
 namespace okge {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: every launcher keeps one of these as a
+// function-local static and opts the kernel in once per device (and again if a larger size is asked for), keyed by
+// hipGetDevice() -- one process per GPU is the normal deployment, but a process driving two devices must work too.
+struct LdsOptIn {
+    std::atomic<size_t> bytes[64];
+    LdsOptIn() { for (auto &b : bytes) b.store(0, std::memory_order_relaxed); }
+};
+inline hipError_t ensure_dynamic_lds(LdsOptIn &state, const void *kernel, size_t shmem)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (shmem <= state.bytes[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);      // (idempotent: a race repeats it)
+    if (e == hipSuccess) state.bytes[dev].store(shmem, std::memory_order_release);
+    return e;
+}
 
 constexpr int NT = 64;             // candidate rows per tile
 constexpr int BC = 64;             // batch rows per chunk

@@ -717,7 +717,10 @@ __global__ __launch_bounds__(256) void rank_metrics_kernel(const int64_t *__rest
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = t;
     }
     __syncthreads();
-    if (threadIdx.x < 7) acc[threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    // atomic: launches of independent stream chains may share one `acc` (PipelinedEvaluator hands every chain its own
+    // and sums them after the join, which also keeps the double sums order-deterministic)
+    if (threadIdx.x < 7)
+        atomicAdd(acc + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // Per-triple score of already encoded rows, Hadamard form (model.py:231-238, :276): one wave per triple.

@@ -661,13 +661,8 @@ template <int KB, int MODE>
 static hipError_t launch_fused_t(const FusedArgs &a, dim3 grid, size_t shmem, hipStream_t st)
 {
     auto k = fused_tile_kernel<KB, MODE>;
-    static size_t configured = 0;
-    if (shmem > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        configured = shmem;
-    }
+    static LdsOptIn lds_opt_in;
+    if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(k), shmem); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(FUSED_THREADS), shmem, st, a);
     return hipGetLastError();
 }
@@ -710,13 +705,8 @@ template <int KB>
 static hipError_t launch_dq_t(const DqArgs &a, int grid_x, size_t shmem, hipStream_t st)
 {
     auto k = dq_kernel<KB>;
-    static size_t configured = 0;
-    if (shmem > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        configured = shmem;
-    }
+    static LdsOptIn lds_opt_in;
+    if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(k), shmem); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid_x), dim3(DqCfg<KB>::THREADS), shmem, st, a);
     return hipGetLastError();
 }
@@ -730,12 +720,8 @@ static hipError_t launch_dq8_t(const DqArgs &a, int grid_x, size_t shmem, hipStr
     const bool db = CAN_DB && db_on;
     auto k = db ? dq8_kernel<KB, CAN_DB> : dq8_kernel<KB, false>;
     if (db) shmem *= 2;
-    static size_t configured = 0;
-    if (shmem > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        configured = shmem;
-    }
+    static LdsOptIn lds_opt_in;
+    if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(k), shmem); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid_x), dim3(512), shmem, st, a);
     return hipGetLastError();
 }

@@ -472,13 +472,8 @@ static hipError_t launch32_t(const FusedArgs &a, dim3 grid, hipStream_t st)
 {
     auto k = fused_tile32_kernel<KB, MODE>;
     const size_t shmem = shmem32<KB>();
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static LdsOptIn lds_opt_in;
+    if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(k), shmem); e != hipSuccess) return e;
     if (std::getenv("OKGE_DEBUG")) {
         int nb = -1;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(k), Tile32Cfg<KB>::THREADS, shmem);

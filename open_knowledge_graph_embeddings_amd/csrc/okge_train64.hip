@@ -538,13 +538,8 @@ static hipError_t launch64_t(const FusedArgs &a, dim3 grid, hipStream_t st)
     static const bool regc_on = [] { const char *e = getenv("OKGE_TILE64_REGC"); return !e || atoi(e) != 0; }();
     auto k = KB <= 13 && regc_on ? fused_tile64_kernel<KB, MODE, (KB <= 13)> : fused_tile64_kernel<KB, MODE, false>;
     const size_t shmem = shmem64<KB>();
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static LdsOptIn lds_opt_in;
+    if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(k), shmem); e != hipSuccess) return e;
     hipLaunchKernelGGL(k, grid, dim3(T64_THREADS), shmem, st, a);
     return hipGetLastError();
 }

@@ -135,7 +135,9 @@ class PipelinedEvaluator:
         """batches: iterable of dataset.CollatedBatch built with is_training_data=False.
         -> (MetricResult with mrr / mr / h1 / h3 / h10 / h50 filled like compute_metrics, number of answer groups)"""
         eng = self.engine
-        acc = torch.zeros(7, dtype=torch.float64, device=self.device)
+        # one meter row per chain: the chains are unordered among each other, so a shared row would be a race between
+        # their meter launches (and the order of the double sums would change from run to run); summed after the join
+        acc = torch.zeros((len(self.streams), 7), dtype=torch.float64, device=self.device)
         main = torch.cuda.current_stream(self.device)
         for st in self.streams:
             st.wait_stream(main)                             # tables / batches were produced on the current stream
@@ -165,11 +167,11 @@ class PipelinedEvaluator:
             N.check(eng.lib.okge_evaluate_batch(ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c),
                                                 cb.filt_ptr.data_ptr(), cb.filt_col.data_ptr() if cb.filt_col.numel() else None,
                                                 cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(), cb.ids.data_ptr(), n_groups,
-                                                x.data_ptr(), x.stride(0), self._ranks[slot].data_ptr(), acc.data_ptr(),
+                                                x.data_ptr(), x.stride(0), self._ranks[slot].data_ptr(), acc[slot].data_ptr(),
                                                 self._ws[slot].data_ptr(), self._ws[slot].numel(), sh, sh), "okge_evaluate_batch")
             keep.append(cb)
         for st in self.streams:
             main.wait_stream(st)
-        a = acc.cpu().tolist()
+        a = acc.sum(0).cpu().tolist()
         del keep
         return _meters(a)

@@ -269,36 +269,124 @@ class ReplicaStep:
     token-pooled models (BASELINE configs[4]: batch-shared candidate lists of a few thousand ids are too short to shard;
     the token tables are small enough to replicate).  Protocol, per step:
         inner.forward_backward(batch, normalizer * world)       own batch, own dropout stream; gradients of the mean
-        ONE all-reduce(sum) over a flat buffer [gradients | batch-norm running statistics]
-        running statistics /= world (every replica normalised with its own batch: the average keeps them identical)
+        exchange (below)                                        gradients summed, batch-norm running statistics averaged
         inner.optimizer_step()                                  the same update everywhere: replicas never drift
-    `inner` must expose grad_tensors() / stat_tensors() (lists of tensors), rebind(list, list) to accept views into the
-    flat buffer, forward_backward(batch, normalizer) and optimizer_step()."""
 
-    def __init__(self, inner, group=None):
+    The exchange moves only what the step touched.  A token-table gradient is dense storage but row-sparse content: a
+    batch's <= N + B entities name a few 10^4 of the 2 x 10^5 token rows (cfg5: 256 MB of dense gradient, ~10-40 MB of
+    touched rows), so all-reducing the whole table would cost several step times on any link.  Instead, while the
+    forward / backward runs on the current stream, a side stream
+        1. marks the rows this replica's batch touches in a byte mask over all sparse tables (ids -> token rows: known
+           from the batch alone, `inner.sparse_grad_rows(batch)`),
+        2. all-reduces the mask with MAX (the union over the replicas, identical everywhere; 250 KB at cfg5),
+        3. lists the union's rows (the one host read of the step; it waits for (1)-(2) only, which finished long before
+           the backward does).
+    Then ONE all-reduce(sum) runs over a flat buffer [dense small gradients | running statistics | the union's rows of
+    every sparse table, packed], and the summed rows are scattered back into the dense gradients the optimiser sweeps.
+    Tables an inner step does not declare sparse (and everything under `sparse=False`) travel whole, as views into the
+    same flat buffer.
+
+    `inner` must expose grad_tensors() / stat_tensors() (lists of tensors), rebind(list, list) to accept views into the
+    flat buffer, forward_backward(batch, normalizer) and optimizer_step(); optionally sparse_grad_rows(batch) ->
+    [(index into grad_tensors(), int tensor of touched rows, duplicates allowed)]."""
+
+    def __init__(self, inner, group=None, sparse=True):
         self.inner, self.group = inner, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        grads, stats = inner.grad_tensors(), inner.stat_tensors()
-        sizes = [(t.numel() + 3) // 4 * 4 for t in grads + stats]                # 16-byte aligned sections
-        dev, dt = grads[0].device, grads[0].dtype
-        self.flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+        self.grads, self.stats = list(inner.grad_tensors()), list(inner.stat_tensors())
+        self.sparse = bool(sparse) and hasattr(inner, "sparse_grad_rows")
+        self.sparse_idx = sorted(inner.sparse_grad_indices()) if self.sparse else []
+        self.dev, self.dt = self.grads[0].device, self.grads[0].dtype
+        self._dense_idx = [i for i in range(len(self.grads)) if i not in self.sparse_idx]
+        dense = [self.grads[i] for i in self._dense_idx] + self.stats
+        self._sizes = [(t.numel() + 3) // 4 * 4 for t in dense]                   # 16-byte aligned sections
+        self._n_dense_grad = sum(self._sizes[:len(self._dense_idx)])
+        self._small = sum(self._sizes)
+        self.flat = None
+        self._bind(self._small)
+        # mask over the rows of all sparse tables, back to back
+        self._row0 = []
+        n = 0
+        for i in self.sparse_idx:
+            self._row0.append(n)
+            n += self.grads[i].shape[0]
+        self.mask = torch.zeros(n, dtype=torch.uint8, device=self.dev) if self.sparse_idx else None
+        self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        self.last_exchanged_elements = 0                                         # diagnostics: floats in the last all-reduce
+        inner.seed = getattr(inner, "seed", 0) + 1000003 * self.rank             # independent dropout masks per replica
+
+    def _bind(self, capacity):
+        """(re)allocate the flat exchange buffer and point the inner step's dense gradients / statistics into its head"""
+        old = self.flat
+        self.flat = torch.zeros(capacity, dtype=self.dt, device=self.dev)
+        grads, stats = list(self.inner.grad_tensors()), list(self.inner.stat_tensors())
         views, off = [], 0
-        for t, n in zip(grads + stats, sizes):
+        for t, n in zip([grads[i] for i in self._dense_idx] + stats, self._sizes):
             v = self.flat[off:off + t.numel()].view_as(t)
             v.copy_(t)
             views.append(v)
             off += n
-        self._n_grad = sum(sizes[:len(grads)])
-        inner.rebind(views[:len(grads)], views[len(grads):])
-        inner.seed = getattr(inner, "seed", 0) + 1000003 * self.rank             # independent dropout masks per replica
+        for k, i in enumerate(self._dense_idx):
+            grads[i] = views[k]
+        self.inner.rebind(grads, views[len(self._dense_idx):])
+        self.grads, self.stats = grads, views[len(self._dense_idx):]
+        del old
 
-    def step(self, batch, normalizer=None):
+    def _union_rows(self, batch):
+        """rows of every sparse table that ANY replica's batch touches: [(grad index, int64 rows)], identical on all ranks"""
+        self.mask.zero_()
+        for k, (i, rows) in enumerate(self.inner.sparse_grad_rows(batch)):
+            assert i == self.sparse_idx[k]
+            self.mask.index_fill_(0, rows.reshape(-1).long() + self._row0[k], 1)
+        dist.all_reduce(self.mask, op=dist.ReduceOp.MAX, group=self.group)
+        out = []
+        for k, i in enumerate(self.sparse_idx):
+            m = self.mask[self._row0[k]:self._row0[k] + self.grads[i].shape[0]]
+            out.append((i, m.nonzero().squeeze(1)))                              # (host read: the sizes of the exchange)
+        return out
+
+    def forward_backward(self, batch, normalizer=None):
+        """the inner step's forward + backward on this replica's batch, scaled so that the exchanged SUM is the mean"""
         if normalizer is None:
             normalizer = float(batch.B) * float(batch.n_candidates)
-        loss = self.inner.forward_backward(batch, normalizer * self.world)
-        if self.world > 1:
+        return self.inner.forward_backward(batch, normalizer * self.world)
+
+    def exchange(self, batch, loss=None):
+        if self.world == 1:
+            return
+        if not self.sparse_idx:
             dist.all_reduce(self.flat, group=self.group)
-            self.flat[self._n_grad:].mul_(1.0 / self.world)
+            self.last_exchanged_elements = self.flat.numel()
+        else:
+            if self.side is not None:
+                main = torch.cuda.current_stream(self.dev)
+                with torch.cuda.stream(self.side):                               # beside the backward still running on `main`
+                    union = self._union_rows(batch)
+                main.wait_stream(self.side)
+            else:
+                union = self._union_rows(batch)
+            need = self._small + sum(r.numel() * self.grads[i].shape[1] for i, r in union)
+            if need > self.flat.numel():
+                self._bind(max(need, 2 * (self.flat.numel() - self._small) + self._small))
+            off = self._small
+            spans = []
+            for i, rows in union:
+                g = self.grads[i]
+                span = self.flat[off:off + rows.numel() * g.shape[1]].view(rows.numel(), g.shape[1])
+                torch.index_select(g, 0, rows, out=span)
+                spans.append((g, rows, span))
+                off += span.numel()
+            dist.all_reduce(self.flat[:off], group=self.group)
+            self.last_exchanged_elements = off
+            for g, rows, span in spans:
+                g.index_copy_(0, rows, span)
+        if self.stats:
+            self.flat[self._n_dense_grad:self._small].mul_(1.0 / self.world)
+        if loss is not None:
             dist.all_reduce(loss, group=self.group)
+
+    def step(self, batch, normalizer=None):
+        loss = self.forward_backward(batch, normalizer)
+        self.exchange(batch, loss)
         self.inner.optimizer_step()
         return loss

@@ -99,3 +99,16 @@ def make_eval_batch(w: Workload, seed):
     b["filt_ptr"] = np.concatenate([[0], np.cumsum(np.bincount(frow, minlength=w.B))]).astype(np.int64)
     b["filt_col"] = fcol.astype(np.int32)
     return b
+
+
+def make_token_matrix(rng, n, vocab, max_len=10, zipf_a=1.2):
+    """(n, max_len) int32 token-id rows of the S-OLP-tok workload (model.py:579-586 layout):
+    BOS=2, 1 + Poisson(2) body tokens from a Zipf vocabulary (ids 4 .. vocab-1; the reference's token ids are
+    frequency-ranked), EOS=3, right-padded with 0."""
+    lens = np.minimum(1 + rng.poisson(2, n), max_len - 2)
+    m = np.zeros((n, max_len), np.int32)
+    m[:, 0] = 2
+    body = (4 + (rng.zipf(zipf_a, (n, max_len)) - 1) % (vocab - 4)).astype(np.int32)
+    for j in range(1, max_len):
+        m[:, j] = np.where(j <= lens, body[:, j], np.where(j == lens + 1, 3, 0))
+    return m

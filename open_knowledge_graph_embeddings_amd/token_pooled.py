@@ -166,6 +166,21 @@ class TokenPooledTrainStep:
                 out += [sl.running_mean, sl.running_var]
         return out
 
+    def sparse_grad_indices(self):
+        """positions in grad_tensors() of the row-sparse gradients (the token tables')"""
+        return [0, 2 if self.entity.bn is not None else 1]
+
+    def sparse_grad_rows(self, batch: H.PrefixBatch):
+        """token-table rows this batch's backward can touch (with repeats; row 0 = padding included, its gradient is 0):
+        the token ids of the candidate + prefix entities, and of the prefix relations -- known from the ids alone"""
+        dev = self.device
+        cand = _i32(batch.cand_ids, dev) if batch.cand_ids is not None else \
+            torch.arange(batch.cand_first, batch.cand_first + batch.n_candidates, dtype=torch.int32, device=dev)
+        ent = torch.cat([x for x in (cand, _i32(batch.po_obj, dev), _i32(batch.sp_subj, dev)) if x is not None]).long()
+        rel = torch.cat([x for x in (_i32(batch.po_rel, dev), _i32(batch.sp_rel, dev)) if x is not None]).long()
+        ie, ir = self.sparse_grad_indices()
+        return [(ie, self.entity.token_ids.index_select(0, ent)), (ir, self.relation.token_ids.index_select(0, rel))]
+
     def rebind(self, grads, stats):
         gi, si = iter(grads), iter(stats)
         for sl in (self.entity, self.relation):
@@ -256,6 +271,11 @@ class TokenPooledTrainStep:
         for sl, bn in getattr(self, "module_batchnorms", ()):          # keep an attached nn.Module's parameters current
             bn.weight.data.copy_(sl.bn_weight)
             bn.bias.data.copy_(sl.bn_bias)
+            # ... and its running statistics, once ReplicaStep.rebind has moved ours into the exchange buffer (the module's
+            # eval-mode encode, state_dict and checkpoints read the module's buffers)
+            if sl.running_mean.data_ptr() != bn.running_mean.data_ptr():
+                bn.running_mean.copy_(sl.running_mean)
+                bn.running_var.copy_(sl.running_var)
 
 
 # ------------------------------------------------------------------------------------------------------------------

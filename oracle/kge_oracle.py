@@ -334,39 +334,57 @@ def batchnorm_eval(x, weight, bias, running_mean, running_var):
 
 
 def unigram_step_forward_backward(kind, We, Wr, ent_tokens, rel_tokens, po, sp, cand_ids, labels, pool="sum",
-                                  bn_ent=None, bn_rel=None, normalizer=None):
-    """AddLossModule.forward + backward for a token-pooled model (trainer.py:48-113 over model.py:762-796), bce loss,
-    dropout 0.  bn_* = dict(weight, bias, running_mean, running_var) or None.  Encoding calls happen in the
+                                  bn_ent=None, bn_rel=None, normalizer=None, p_drop=0.0, keep=None, want_outputs=True):
+    """AddLossModule.forward + backward for a token-pooled model (trainer.py:48-113 over model.py:762-796), bce loss.
+    bn_* = dict(weight, bias, running_mean, running_var) or None.  Encoding calls happen in the
     reference's order -- candidates, po rows, sp rows -- each with ITS OWN batch statistics.
+    Dropout (model.py:783-784: the LAST stage of _encode, after pooling and batch-norm): `keep` = dict of boolean masks
+    cand / po_rel / po_ent / sp_ent / sp_rel (this build's Philox masks, or masks captured from the reference), rows
+    scaled by 1/(1-p_drop).  `labels`: dense (B,N) array, or (rows, cols) coordinates of the positives.
     Returns dict(loss, outputs, dWe, dWr, d_bn_ent (w,b), d_bn_rel (w,b))."""
-    def enc(W, tokens, ids, bn):
-        x, paux = token_pool(W, tokens, ids, pool)
-        if bn is None:
-            return x, (paux, None)
-        y, baux = batchnorm_train(x, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"])
-        return y, (paux, baux)
+    keep = keep or {}
+    dt = We.dtype
+    scale = dt.type(1.0 / (1.0 - p_drop)) if p_drop > 0 else dt.type(1.0)
 
-    C, auxC = enc(We, ent_tokens, cand_ids, bn_ent)
+    def enc(W, tokens, ids, bn, mask):
+        x, paux = token_pool(W, tokens, ids, pool)
+        baux = None
+        if bn is not None:
+            x, baux = batchnorm_train(x, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"])
+        m = None
+        if mask is not None and p_drop > 0:
+            m = mask.astype(dt) * scale
+            x = x * m
+        return x, (paux, baux, m)
+
+    C, auxC = enc(We, ent_tokens, cand_ids, bn_ent, keep.get("cand"))
     parts = []
     if po is not None:
-        r, auxr = enc(Wr, rel_tokens, po[0], bn_rel)
-        e, auxe = enc(We, ent_tokens, po[1], bn_ent)
+        r, auxr = enc(Wr, rel_tokens, po[0], bn_rel, keep.get("po_rel"))
+        e, auxe = enc(We, ent_tokens, po[1], bn_ent, keep.get("po_ent"))
         parts.append((DIR_PO, e, r, auxe, auxr))
     if sp is not None:
-        e, auxe = enc(We, ent_tokens, sp[0], bn_ent)
-        r, auxr = enc(Wr, rel_tokens, sp[1], bn_rel)
+        e, auxe = enc(We, ent_tokens, sp[0], bn_ent, keep.get("sp_ent"))
+        r, auxr = enc(Wr, rel_tokens, sp[1], bn_rel, keep.get("sp_rel"))
         parts.append((DIR_SP, e, r, auxe, auxr))
     X = np.concatenate([score_prefix(kind, d_, e, r, C) for d_, e, r, _, _ in parts])
     B, N = X.shape
     normalizer = float(B * N) if normalizer is None else normalizer
+    if isinstance(labels, tuple):
+        y = np.zeros((B, N), X.dtype)
+        y[np.asarray(labels[0], np.int64), np.asarray(labels[1], np.int64)] = 1
+        labels = y
     loss, g = loss_and_dscore(X, labels, LOSS_BCE, 0.0)
     G = (g / X.dtype.type(normalizer)).astype(X.dtype)
+    del g, labels
     dWe, dWr = np.zeros_like(We), np.zeros_like(Wr)
     dbe = [np.zeros(We.shape[1], We.dtype), np.zeros(We.shape[1], We.dtype)]
     dbr = [np.zeros(Wr.shape[1], Wr.dtype), np.zeros(Wr.shape[1], Wr.dtype)]
 
     def back(d_rows, aux, W_grad, bn, acc):
-        paux, baux = aux
+        paux, baux, m = aux
+        if m is not None:
+            d_rows = d_rows * m
         if bn is not None:
             d_rows, dw, db = batchnorm_train_backward(d_rows, bn["weight"], baux)
             acc[0] += dw
@@ -384,7 +402,7 @@ def unigram_step_forward_backward(kind, We, Wr, ent_tokens, rel_tokens, po, sp, 
         back(dr, auxr, dWr, bn_rel, dbr)
         row += e.shape[0]
     back(dC, auxC, dWe, bn_ent, dbe)
-    return dict(loss=float(loss), outputs=X, dWe=dWe, dWr=dWr, d_bn_ent=tuple(dbe), d_bn_rel=tuple(dbr))
+    return dict(loss=float(loss), outputs=X if want_outputs else None, dWe=dWe, dWr=dWr, d_bn_ent=tuple(dbe), d_bn_rel=tuple(dbr))
 
 
 # ------------------------------------------------------------------------------------------------

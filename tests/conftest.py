@@ -50,3 +50,14 @@ def okge_lib():
     """The product C-ABI library; GPU tests fail loudly (not skip) if it cannot be loaded."""
     from open_knowledge_graph_embeddings_amd import _native
     return _native.lib()
+
+
+@pytest.fixture
+def production_config(monkeypatch):
+    """The configuration production runs: OKGE_VALIDATE unset -- no host-side id range checks, no sync per call; the
+    kernels' own id guard (checked_row -> okge_id_errors) is the only net.  Used by the full-size / real-data parity tests;
+    at teardown the device-side guard must not have seen a single bad id."""
+    from open_knowledge_graph_embeddings_amd import _native, hotpath
+    monkeypatch.setattr(hotpath, "VALIDATE", False)
+    yield
+    assert _native.id_errors() == 0

@@ -66,6 +66,7 @@ def test_oracle_on_fb15k237_batch():
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("production_config")
 def test_hip_on_fb15k237_batch(okge_lib):
     from open_knowledge_graph_embeddings_amd import hotpath as H
     z = golden("g10_fb15k237_batch")

@@ -344,6 +344,7 @@ def test_philox_dropout_matches_oracle_masks(hp, scorer):
     np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
 
 
+@pytest.mark.usefixtures("production_config")
 def test_full_size_distmult_d512_sampled(hp):
     """configs[2]: FB15k-237 LookupDistmultRelationModel d=512, B=512, batch-shared sampled candidates N=10 000."""
     n_ent, n_rel, d = 14543, 239, 512
@@ -369,6 +370,7 @@ def test_full_size_distmult_d512_sampled(hp):
 
 
 # ------------------------------------------------------------------------------- BASELINE.json full size
+@pytest.mark.usefixtures("production_config")
 def test_full_size_fb15k237_shape(hp):
     """configs[1]: |E|=14543, |R|=239, d=200, B=512 (256 po + 256 sp), N=14541, 1-vs-all, BCE."""
     n_ent, n_rel, d = 14543, 239, 200
@@ -392,6 +394,52 @@ def test_full_size_fb15k237_shape(hp):
     b2 = make_batch(z, cand[sub], n_ent)
     out_sub = hp.score(Et, Rt, "complex", b2).cpu().numpy()
     np.testing.assert_array_equal(out_sub, out[:, sub])
+
+
+def _full_size_case(hp, scorer, n_ent, n_rel, d, n_po, n_sp, loss_kind, smoothing, p_ent, scale, seed):
+    """one BASELINE-sized step against the oracle: scores, loss, full dE / dR; Philox dropout on when p_ent > 0"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    E, R, z, cand, y = random_problem(seed, n_ent, n_rel, d, n_po, n_sp, None, max_pos=8)
+    E *= scale
+    kw, batch = {}, make_batch(z, cand, n_ent, labels=y)
+    if p_ent > 0:
+        sd, step = 0x5EED5EED, 3
+        kw = dict(p_ent=p_ent, p_rel=0.0, keep_cand=ko.dropout_keep_mask(sd, H.STREAM_CAND, step, len(cand), d, p_ent),
+                  keep_po_ent=ko.dropout_keep_mask(sd, H.STREAM_PO_ENT, step, n_po, d, p_ent),
+                  keep_sp_ent=ko.dropout_keep_mask(sd, H.STREAM_SP_ENT, step, n_sp, d, p_ent))
+        batch.drop_cand = H.DropoutSpec(p_ent, sd, H.STREAM_CAND, step)
+        batch.drop_po_ent = H.DropoutSpec(p_ent, sd, H.STREAM_PO_ENT, step)
+        batch.drop_sp_ent = H.DropoutSpec(p_ent, sd, H.STREAM_SP_ENT, step)
+    ref = oracle_step(scorer, E, R, z, cand, y, loss_kind, smoothing, **kw)
+    Et, Rt = dev(E), dev(R)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss = hp.forward_backward(Et, Rt, scorer, batch, dE, dR, loss=loss_kind, label_smoothing=smoothing)
+    out = hp.score(Et, Rt, scorer, batch).cpu().numpy()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out, ref["outputs"], rtol=0, atol=SCORE_ATOL)
+    assert abs(loss.item() - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+    np.testing.assert_allclose(dE.cpu().numpy(), ref["dE"], rtol=0, atol=3e-5 * np.abs(ref["dE"]).max())
+    np.testing.assert_allclose(dR.cpu().numpy(), ref["dR"], rtol=0, atol=3e-5 * np.abs(ref["dR"]).max())
+
+
+@pytest.mark.usefixtures("production_config")
+def test_full_size_fb15k237_plumbing_shape(hp):
+    """configs[0]: |E|=14543, |R|=239, d=64, B=128 (64 po + 64 sp), N=14541, 1-vs-all, BCE, input_dropout 0.4
+    (config/fb15k237/fb15k237-complex-kge.yaml with the README's d=64 / batch 128 overrides)."""
+    _full_size_case(hp, "complex", 14543, 239, 64, 64, 64, "bce", 0.0, 0.4, 0.5, 2468)
+
+
+@pytest.mark.usefixtures("production_config")
+def test_full_size_fb15k237_shape_kl(hp):
+    """configs[1] with the softmax / KL loss (trainer.py:99-101): |E|=14543, d=200, B=512, N=14541, dropout 0.4 --
+    the row log-sum-exp over all 14 541 candidates (stats pass + merge) at the full size."""
+    _full_size_case(hp, "complex", 14543, 239, 200, 256, 256, "kl", 0.0, 0.4, 1 / 3.0, 1357)
+
+
+@pytest.mark.usefixtures("production_config")
+def test_full_size_fb15k237_shape_smoothing_dropout(hp):
+    """configs[1] as the YAML trains it: BCE, input_dropout 0.4, plus label smoothing 0.1 (trainer.py:103-105)"""
+    _full_size_case(hp, "complex", 14543, 239, 200, 256, 256, "bce", 0.1, 0.4, 1 / 3.0, 97531)
 
 
 # --------------------------------------------------------------------------------------- HIP-graph replay

@@ -18,7 +18,7 @@ import torch
 
 from oracle import kge_oracle as ko
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("production_config")]   # OKGE_VALIDATE off, like production
 
 D, B, N_REL = 256, 4096, 100_000
 P_ENT, P_REL, SEED, STEP = 0.4, 0.2, 77, 5

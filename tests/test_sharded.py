@@ -284,6 +284,86 @@ def _replica_step_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
+class _ToySparseInner(_ToyInner):
+    """+ one row-sparse table gradient: each batch touches the rows it names"""
+
+    def __init__(self, rank):
+        super().__init__(rank)
+        self.table = torch.zeros((50, 4))
+        self.gt = torch.zeros((50, 4))
+
+    def grad_tensors(self):
+        return [self.g, self.gt, self.g2]
+
+    def sparse_grad_indices(self):
+        return [1]
+
+    def sparse_grad_rows(self, batch):
+        return [(1, batch.rows)]
+
+    def rebind(self, grads, stats):
+        self.g, self.gt, self.g2 = grads
+        (self.stat,) = stats
+
+    def forward_backward(self, batch, normalizer):
+        for r in batch.rows.reshape(-1).tolist():
+            self.gt[r] += (r + 1.0) / normalizer
+        return super().forward_backward(batch, normalizer)
+
+    def optimizer_step(self):
+        self.table -= self.gt
+        self.gt.zero_()
+        super().optimizer_step()
+
+
+def _replica_sparse_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    inner = _ToySparseInner(rank)
+    st = ReplicaStep(inner)
+    sent = []
+    for step in range(3):
+        class B:                                                    # noqa: D401  (duck-typed batch)
+            B, n_candidates = 2, 5
+            rows = torch.tensor([[0, 3 + rank, 7, 7], [40 + step, 3 + rank, 0, 11 * rank]])      # repeats, overlap, own rows
+
+            def __getitem__(self, k):
+                return torch.arange(5, dtype=torch.float32) * (rank + 1)
+        st.step(B())
+        sent.append(st.last_exchanged_elements)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), w=inner.w.numpy(), stat=inner.stat.numpy(), table=inner.table.numpy(),
+             sent=np.asarray(sent), gt=inner.gt.numpy())
+    dist.destroy_process_group()
+
+
+def test_replica_step_sparse_rows_gloo():
+    """touched-row exchange: only the union of the replicas' touched table rows travels (plus the small dense head);
+    tables stay identical and equal to the dense sum"""
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_replica_sparse_worker, args=(world, port, outdir), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
+    np.testing.assert_array_equal(parts[0]["table"], parts[1]["table"])
+    np.testing.assert_array_equal(parts[0]["w"], parts[1]["w"])
+    np.testing.assert_array_equal(parts[0]["stat"], parts[1]["stat"])
+    norm = 2 * 5 * world
+    want = np.zeros((50, 4), np.float32)
+    for step in range(3):
+        for rank in range(world):
+            for r in [0, 3 + rank, 7, 7, 40 + step, 3 + rank, 0, 11 * rank]:
+                want[r] -= (r + 1.0) / norm
+    np.testing.assert_allclose(parts[0]["table"], want, rtol=1e-6)
+    assert not parts[0]["gt"].any()
+    # union per step: rows {0, 3, 4, 7, 11, 40 + step} = 6 rows x 4 columns, + the dense head (5 + 3 -> 8 + 4, stat 2 -> 4)
+    assert parts[0]["sent"].tolist() == [16 + 24] * 3 and 16 + 24 < 50 * 4
+
+
 def test_replica_step_protocol_gloo():
     """ReplicaStep (used for the token-pooled models): summed gradients of the mean loss, averaged running statistics,
     identical parameters on every rank"""
@@ -545,7 +625,52 @@ def test_replica_step_token_pooled_one_rank(okge_lib):
             np.testing.assert_allclose(a.W.cpu().numpy(), b_.W.cpu().numpy(), rtol=1e-4, atol=1e-5)
             np.testing.assert_allclose(a.bn.cpu().numpy(), b_.bn.cpu().numpy(), rtol=1e-4, atol=1e-5)
             np.testing.assert_allclose(a.running_mean.cpu().numpy(), b_.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
-        assert inner.entity.dW.data_ptr() >= rep.flat.data_ptr() and float(rep.flat.abs().sum()) >= 0
+        lo, hi = rep.flat.data_ptr(), rep.flat.data_ptr() + 4 * rep.flat.numel()
+        assert lo <= inner.entity.d_bn.data_ptr() < hi and lo <= inner.relation.running_var.data_ptr() < hi
+        assert not (lo <= inner.entity.dW.data_ptr() < hi)          # token tables: row-sparse exchange, not in the flat head
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replica_step_keeps_module_running_statistics(okge_lib):
+    """ReplicaStep around model.train_step(): rebind moves the step's running statistics into the exchange buffer; the
+    MODULE's BatchNorm buffers (what eval-mode encode, state_dict and checkpoints read) must keep following them"""
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.dataset import EntityRelationDatasetMeta
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
+    from open_knowledge_graph_embeddings_amd.token_pooled import UnigramPoolingComplexRelationModel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        rng = np.random.default_rng(11)
+        n_ent, n_rel, vocab, L, d = 120, 20, 60, 4, 64
+        md = EntityRelationDatasetMeta(entities_size=n_ent, relations_size=n_rel, entity_tokens_size=vocab, relation_tokens_size=vocab,
+                                       max_length=(L, L),
+                                       entity_id_to_tokens_map=[rng.integers(1, vocab, L).tolist() for _ in range(n_ent)],
+                                       relation_id_to_tokens_map=[rng.integers(1, vocab, L).tolist() for _ in range(n_rel)])
+        m = UnigramPoolingComplexRelationModel(entity_slot_size=d, relation_slot_size=d, train_data=md, pool="sum",
+                                               normalize="batchnorm", dropout=0.0, init_std=0.3).cuda()
+        rep = ReplicaStep(m.train_step(lr=0.1))
+        t = lambda x: torch.from_numpy(x).cuda()      # noqa: E731
+        for step in range(3):
+            b, nc = 16, 64
+            rows = np.arange(2 * b, dtype=np.int32)
+            cols = np.sort(rng.integers(0, nc, 2 * b)).astype(np.int32)
+            rep.step(PrefixBatch(po_rel=t(rng.integers(2, n_rel, b).astype(np.int32)), po_obj=t(rng.integers(2, n_ent, b).astype(np.int32)),
+                                 sp_subj=t(rng.integers(2, n_ent, b).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, b).astype(np.int32)),
+                                 pos_row=t(rows), pos_col=t(cols), cand_ids=t(rng.permutation(np.arange(2, n_ent))[:nc].astype(np.int32))))
+        torch.cuda.synchronize()
+        inner = rep.inner
+        for sl, bn in ((inner.entity, m.entity_batchnorm), (inner.relation, m.relation_batchnorm)):
+            assert float((bn.running_mean - 0).abs().max()) > 0 and float((bn.running_var - 1).abs().max()) > 0
+            np.testing.assert_array_equal(bn.running_mean.cpu().numpy(), sl.running_mean.cpu().numpy())
+            np.testing.assert_array_equal(bn.running_var.cpu().numpy(), sl.running_var.cpu().numpy())
+            np.testing.assert_array_equal(bn.weight.data.cpu().numpy(), sl.bn_weight.cpu().numpy())
+        assert "entity_batchnorm.running_mean" in m.state_dict()
     finally:
         dist.destroy_process_group()
 

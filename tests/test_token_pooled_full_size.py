@@ -1,0 +1,155 @@
+"""BASELINE configs[4] at its real size: the token-pooled step (UnigramPoolingComplexRelationModel, openkge/model.py:762-786
+and :670-712 behind AddLossModule, trainer.py:48-113) on the S-OLP-tok workload of SURVEY.md section 8d --
+|E| = 2.5 M entities x L = 10 tokens from a 200 k Zipf vocabulary, |R| = 100 k relations over a 50 k vocabulary, d = 256,
+B = 4096 prefixes, batch-shared candidate list N = 8192, sum pooling + BatchNorm1d, Philox dropout ON.
+
+Unlike configs[3] this shape CAN be recomputed densely on the host (33.5 M scores), so the whole step is compared with the
+NumPy oracle in float64: loss, the full (B, N) score block, the FULL token-table gradients dWe (200 k x 256) and dWr
+(50 k x 256), the batch-norm gradients and the running statistics after the five encode calls.  What this size exercises
+and the small G9 cases cannot: hot-token accumulation in LDS under real Zipf skew (BOS / EOS sit in all 12 288 entity rows
+of the step), ~10^5 float atomics per hot token row, Chan-merged batch-norm statistics over 8 192 rows in 512 row blocks,
+token-id rows gathered from a 100 MB id matrix.
+
+The same step then runs through sharded.ReplicaStep with a one-rank group (gradients and running statistics as views into
+the flat exchange buffer -- the multi-GPU mode of this config)."""
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge_oracle as ko
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("production_config")]   # OKGE_VALIDATE off, like production
+
+N_ENT, N_REL, D, B, N_CAND, L, V_ENT, V_REL = 2_500_000, 100_000, 256, 4096, 8192, 10, 200_000, 50_000
+P_DROP, SEED = 0.1, 20240917
+
+
+@pytest.fixture(scope="module")
+def problem():
+    from open_knowledge_graph_embeddings_amd.synthetic import make_token_matrix
+    rng = np.random.default_rng(5)
+    z = dict(ent_tokens=make_token_matrix(rng, N_ENT, V_ENT, L), rel_tokens=make_token_matrix(rng, N_REL, V_REL, L),
+             We=(rng.standard_normal((V_ENT, D), dtype=np.float32) * np.float32(0.1)),
+             Wr=(rng.standard_normal((V_REL, D), dtype=np.float32) * np.float32(0.1)),
+             bn_e_w=rng.uniform(0.2, 1.0, D).astype(np.float32), bn_e_b=(rng.standard_normal(D) * 0.05).astype(np.float32),
+             bn_r_w=rng.uniform(0.2, 1.0, D).astype(np.float32), bn_r_b=(rng.standard_normal(D) * 0.05).astype(np.float32),
+             po_rel=rng.integers(2, N_REL, B // 2).astype(np.int32),
+             po_obj=(2 + (rng.zipf(1.1, B // 2) - 1) % (N_ENT - 2)).astype(np.int32),        # Zipf(1.1) prefix entities, SURVEY 8d
+             sp_subj=(2 + (rng.zipf(1.1, B // 2) - 1) % (N_ENT - 2)).astype(np.int32),
+             sp_rel=rng.integers(2, N_REL, B // 2).astype(np.int32),
+             cand=(rng.choice(N_ENT - 2, N_CAND, replace=False) + 2).astype(np.int32))
+    rows = np.concatenate([np.arange(B), rng.integers(0, B, B // 4)])                         # 1.25 positives per prefix
+    cols = np.concatenate([rng.integers(0, N_CAND, B), rng.integers(0, N_CAND, B // 4)])
+    key = np.unique(cols.astype(np.int64) * B + rows)                                         # sorted by (col, row)
+    z["pos_row"], z["pos_col"] = (key % B).astype(np.int32), (key // B).astype(np.int32)
+    # hot tokens really are hot: BOS in every row, the most frequent body token in > 5 % of the candidate rows
+    tok = z["ent_tokens"][z["cand"]]
+    assert (tok[:, 0] == 2).all() and (tok == 4).any(axis=1).mean() > 0.05
+    return z
+
+
+def _oracle(z):
+    f64 = lambda a: a.astype(np.float64)                                      # noqa: E731
+    d = D
+    bn_e = dict(weight=f64(z["bn_e_w"]), bias=f64(z["bn_e_b"]), running_mean=np.zeros(d), running_var=np.ones(d))
+    bn_r = dict(weight=f64(z["bn_r_w"]), bias=f64(z["bn_r_b"]), running_mean=np.zeros(d), running_var=np.ones(d))
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    km = lambda stream, n: ko.dropout_keep_mask(SEED, stream, 1, n, d, P_DROP)           # noqa: E731  (first step: step = 1)
+    keep = dict(cand=km(H.STREAM_CAND, N_CAND), po_ent=km(H.STREAM_PO_ENT, B // 2), po_rel=km(H.STREAM_PO_REL, B // 2),
+                sp_ent=km(H.STREAM_SP_ENT, B // 2), sp_rel=km(H.STREAM_SP_REL, B // 2))
+    out = ko.unigram_step_forward_backward(ko.COMPLEX, f64(z["We"]), f64(z["Wr"]), z["ent_tokens"], z["rel_tokens"],
+                                           (z["po_rel"], z["po_obj"]), (z["sp_subj"], z["sp_rel"]), z["cand"],
+                                           (z["pos_row"], z["pos_col"]), pool="sum", bn_ent=bn_e, bn_rel=bn_r,
+                                           p_drop=P_DROP, keep=keep)
+    out["bn_e"], out["bn_r"] = bn_e, bn_r
+    return out
+
+
+def _step(z):
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()           # noqa: E731
+    e = TokenSlot(t(z["We"]), t(z["ent_tokens"]), "sum", True, t(z["bn_e_w"]), t(z["bn_e_b"]))
+    r = TokenSlot(t(z["Wr"]), t(z["rel_tokens"]), "sum", True, t(z["bn_r_w"]), t(z["bn_r_b"]))
+    return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=P_DROP, seed=SEED)
+
+
+def _batch(z):
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()           # noqa: E731
+    return PrefixBatch(po_rel=t(z["po_rel"]), po_obj=t(z["po_obj"]), sp_subj=t(z["sp_subj"]), sp_rel=t(z["sp_rel"]),
+                       pos_row=t(z["pos_row"]), pos_col=t(z["pos_col"]), cand_ids=t(z["cand"]))
+
+
+def _check(st, ref, loss, scores=None):
+    assert abs(float(loss[0]) - ref["loss"]) <= 3e-5 * abs(ref["loss"])
+    if scores is not None:
+        x = scores.cpu().numpy()
+        assert np.abs(ref["outputs"]).max() > 2.0                       # scores well off zero: the sigmoid is exercised
+        np.testing.assert_allclose(x, ref["outputs"], rtol=0, atol=1e-4)                       # north_star bound
+    e, r = st.entity, st.relation
+    for mine, want in ((e.dW, ref["dWe"]), (r.dW, ref["dWr"])):
+        got = mine.cpu().numpy()
+        # the FULL tables: every row, incl. the hot tokens' rows (largest entries) and the rows no token of the batch touches
+        np.testing.assert_allclose(got, want, rtol=0, atol=5e-5 * np.abs(want).max())
+        assert not got[0].any()                                         # padding_idx row: no gradient (model.py:600-606)
+        untouched = np.abs(want).sum(axis=1) == 0
+        assert untouched.sum() > 1000 and not got[untouched].any()
+        rel = np.abs(got - want).sum() / np.abs(want).sum()
+        assert rel < 2e-5, rel
+    for sl, g, bn in ((e, ref["d_bn_ent"], ref["bn_e"]), (r, ref["d_bn_rel"], ref["bn_r"])):
+        d = sl.d
+        np.testing.assert_allclose(sl.d_bn[:d].cpu().numpy(), g[0], rtol=0, atol=5e-5 * np.abs(g[0]).max())
+        np.testing.assert_allclose(sl.d_bn[d:].cpu().numpy(), g[1], rtol=0, atol=5e-5 * np.abs(g[1]).max())
+        np.testing.assert_allclose(sl.running_mean.cpu().numpy(), bn["running_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sl.running_var.cpu().numpy(), bn["running_var"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def reference(problem):
+    return _oracle(problem)
+
+
+def test_token_pooled_step_at_config5_size(okge_lib, problem, reference):
+    st = _step(problem)
+    scores = torch.empty((B, N_CAND), device="cuda:0")
+    loss = st.forward_backward(_batch(problem), scores=scores)
+    torch.cuda.synchronize()
+    _check(st, reference, loss, scores)
+    # the optimiser sweep at this size: dense Adagrad over both token tables and the batch-norm parameters
+    We, sums = problem["We"].astype(np.float64), np.zeros((V_ENT, D))
+    ko.adagrad_step(We, reference["dWe"], sums, 0.1)
+    st.optimizer_step()
+    torch.cuda.synchronize()
+    got = st.entity.W.cpu().numpy()
+    # first Adagrad step: p -= lr * g / (|g| + 1e-8): rows with |g| ~ 1e-8 amplify fp32 gradient noise; compare where
+    # the gradient is well above it and require the rest to have moved by at most lr
+    big = np.abs(reference["dWe"]) > 1e-6 * np.abs(reference["dWe"]).max()
+    np.testing.assert_allclose(got[big], We[big], rtol=0, atol=2e-3)
+    assert np.isclose(got[big], We[big], rtol=0, atol=2e-5).mean() > 0.999
+    assert np.abs(got - problem["We"]).max() <= 0.1 * (1 + 1e-5)
+    assert float(st.entity.dW.abs().sum()) == 0                       # zero_grad fused into the sweep
+
+
+def test_token_pooled_replica_step_one_rank_at_config5_size(okge_lib, problem, reference):
+    """the multi-GPU mode of this config (replicas; sharded.ReplicaStep) with a one-rank group: gradients and running
+    statistics live in the flat exchange buffer, results unchanged"""
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        inner = _step(problem)
+        rep = ReplicaStep(inner)
+        assert inner.seed == SEED                                      # rank 0 keeps the seed
+        lo, hi = rep.flat.data_ptr(), rep.flat.data_ptr() + rep.flat.numel() * 4
+        for t_ in inner.grad_tensors() + inner.stat_tensors():
+            assert lo <= t_.data_ptr() < hi
+        loss = rep.forward_backward(_batch(problem))
+        torch.cuda.synchronize()
+        _check(inner, reference, loss)
+    finally:
+        dist.destroy_process_group()

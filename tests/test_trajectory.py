@@ -164,6 +164,7 @@ def _batch(H, z, pre, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("production_config")
 def test_hip_g7_trajectory_and_ranks(okge_lib):
     from open_knowledge_graph_embeddings_amd import hotpath as H
     from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
@@ -195,6 +196,7 @@ def test_hip_g7_trajectory_and_ranks(okge_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("production_config")
 def test_hip_g11_trajectory_and_mrr(okge_lib):
     """the north-star 'MRR parity' on the HIP path: 30 reference steps at the BASELINE size, then filtered MRR"""
     from open_knowledge_graph_embeddings_amd import hotpath as H
@@ -236,6 +238,7 @@ def test_hip_g11_trajectory_and_mrr(okge_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("production_config")
 def test_hip_ranks_on_reference_trained_tables(okge_lib):
     """rank mismatch rate of the HIP path against the reference on IDENTICAL trained tables (expected 0; a score pair
     closer than fp32 summation noise may swap)"""

@@ -151,14 +151,10 @@ def main():
         from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
         n_ent, n_rel, d, B, N, L, vt_e, vt_r = 2_500_000, 100_000, 256, 4096, 8192, 10, 200_000, 50_000
 
+        from open_knowledge_graph_embeddings_amd.synthetic import make_token_matrix
+
         def tokens(n, vocab):
-            lens = np.minimum(1 + rng.poisson(2, n), L - 2)
-            m = np.zeros((n, L), np.int32)
-            m[:, 0] = 2
-            body = (4 + (rng.zipf(1.2, (n, L)) - 1) % (vocab - 4)).astype(np.int32)
-            for j in range(1, L):
-                m[:, j] = np.where(j <= lens, body[:, j], np.where(j == lens + 1, 3, 0))
-            return t(m)
+            return t(make_token_matrix(rng, n, vocab, L))
         ent = TokenSlot(torch.randn((vt_e, d), device=dev) * 0.1, tokens(n_ent, vt_e), "sum", True)
         rel = TokenSlot(torch.randn((vt_r, d), device=dev) * 0.1, tokens(n_rel, vt_r), "sum", True)
         step = TokenPooledTrainStep(ent, rel, "complex", lr=0.1, dropout=0.1, seed=1)
