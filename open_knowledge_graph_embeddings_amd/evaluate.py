@@ -35,8 +35,11 @@ class FusedEvaluator:
     1 chain 0.056 ms, 2 chains 0.046, 3 chains 0.043, 4 chains 0.043-0.048.
     Slot sizes up to 256, eval mode; PipelinedEvaluator (materialised scores) covers the rest."""
 
-    def __init__(self, E, R, scorer, engine=None, run_len=48, two_streams=True, n_streams=None):
+    def __init__(self, E, R, scorer, engine=None, run_len=48, two_streams=True, n_streams=None, collect_ranks=False):
         self.E, self.R, self.scorer = E, R, scorer
+        # collect_ranks: keep every answer group's rank (self.ranks after run(): int64, batches in order, groups in the
+        # batch's row / group order) instead of treating the ranks as scratch -- for parity tests and error analysis
+        self.collect_ranks, self.ranks, self._kept = bool(collect_ranks), None, []
         self.device = E.device
         self.engine = engine or H.HotPath(self.device)
         self.run_len = int(run_len)
@@ -67,18 +70,29 @@ class FusedEvaluator:
                                    device=self.device)
             self._ranks = torch.empty(max(slots * n_groups, 4096, 0 if self._ranks is None else self._ranks.numel()),
                                       dtype=torch.int64, device=self.device)
-        for i in range(n):                                   # the ranks themselves are scratch here: the regions rotate
-            self._arr[i].rank_offset = (i % slots) * n_groups
+        ranks = self._ranks
+        if self.collect_ranks:                               # one region per batch, kept: a fresh block per issued run
+            counts = [int(self._arr[i].n_groups) for i in range(n)]
+            ranks = torch.empty(max(sum(counts), 1), dtype=torch.int64, device=self.device)
+            off = 0
+            for i in range(n):
+                self._arr[i].rank_offset = off
+                off += counts[i]
+            self._kept.append(ranks[:off])
+        else:
+            for i in range(n):                               # the ranks themselves are scratch here: the regions rotate
+                self._arr[i].rank_offset = (i % slots) * n_groups
         handles = (ctypes.c_void_p * self.n_streams)(stream_h, *[ctypes.c_void_p(x.cuda_stream) for x in self.sides])
         # (the library orders the current stream behind the other streams' share at the end of every call; letting the
         #  chains run on across calls instead measured no faster)
-        N.check(self.engine.lib.okge_evaluate_fused_batches(ctypes.byref(self._t), self._arr, n, self._ranks.data_ptr(),
+        N.check(self.engine.lib.okge_evaluate_fused_batches(ctypes.byref(self._t), self._arr, n, ranks.data_ptr(),
                                                             acc.data_ptr(), self._ws.data_ptr(), self._ws.numel(), handles,
                                                             self.n_streams), "okge_evaluate_fused_batches")
 
     def run(self, batches):
         """batches: iterable of dataset.CollatedBatch built with is_training_data=False -> (MetricResult, #groups)"""
         acc = torch.zeros(7, dtype=torch.float64, device=self.device)
+        self._kept = []
         main = torch.cuda.current_stream(self.device)
         stream_h = ctypes.c_void_p(main.cuda_stream)
         n, need, n_groups, run = 0, 0, 0, min(2 * self.n_streams, self.run_len)   # two batches per chain, then x4:
@@ -95,6 +109,9 @@ class FusedEvaluator:
             self._issue(n, need, n_groups, acc, stream_h)
         out = _meters(acc.cpu().tolist())          # (synchronises: every kernel that read a batch has finished)
         keep.clear()
+        if self.collect_ranks:
+            self.ranks = torch.cat(self._kept) if self._kept else torch.zeros(0, dtype=torch.int64, device=self.device)
+            self._kept = []
         return out
 
 
@@ -106,8 +123,9 @@ class PipelinedEvaluator:
     this hardware; the first version ordered a scoring and a ranking stream with two events per batch), so the ranking of
     one batch runs beside the scoring of the next ones.  Meters accumulate on the device; one host read at the end."""
 
-    def __init__(self, E, R, scorer, engine=None, n_streams=3):
+    def __init__(self, E, R, scorer, engine=None, n_streams=3, collect_ranks=False):
         self.E, self.R, self.scorer = E, R, scorer
+        self.collect_ranks, self.ranks = bool(collect_ranks), None          # as FusedEvaluator
         self.device = E.device
         self.engine = engine or H.HotPath(self.device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n_streams)))]
@@ -141,16 +159,22 @@ class PipelinedEvaluator:
         main = torch.cuda.current_stream(self.device)
         for st in self.streams:
             st.wait_stream(main)                             # tables / batches were produced on the current stream
-        keep = []                                            # every batch stays referenced until the chains have joined
+        keep, kept = [], []                                  # every batch stays referenced until the chains have joined
         for i, cb in enumerate(batches):
             slot = i % len(self.streams)
             st = self.streams[slot]
             x = self._buffer(slot, cb.batch.B, cb.n_cand)
             n_groups = int(cb.grp_ptr.numel()) - 1
-            if self._ranks[slot] is None or self._ranks[slot].numel() < n_groups:
-                st.synchronize()
-                self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
-                self._ranks[slot].record_stream(st)
+            if self.collect_ranks:                           # a block of its own per batch, kept until the end
+                rk = torch.empty(max(n_groups, 1), dtype=torch.int64, device=self.device)
+                rk.record_stream(st)
+                kept.append(rk[:n_groups])
+            else:
+                if self._ranks[slot] is None or self._ranks[slot].numel() < n_groups:
+                    st.synchronize()
+                    self._ranks[slot] = torch.empty(max(n_groups, 1024), dtype=torch.int64, device=self.device)
+                    self._ranks[slot].record_stream(st)
+                rk = self._ranks[slot]
             b, pb, c = cb.batch, self._pb, self._c
             pb.po_rel, pb.po_obj = (b.po_rel.data_ptr(), b.po_obj.data_ptr()) if b.po_rel is not None else (None, None)
             pb.sp_subj, pb.sp_rel = (b.sp_subj.data_ptr(), b.sp_rel.data_ptr()) if b.sp_subj is not None else (None, None)
@@ -167,11 +191,13 @@ class PipelinedEvaluator:
             N.check(eng.lib.okge_evaluate_batch(ctypes.byref(self._t), ctypes.byref(pb), ctypes.byref(c),
                                                 cb.filt_ptr.data_ptr(), cb.filt_col.data_ptr() if cb.filt_col.numel() else None,
                                                 cb.row_ptr.data_ptr(), cb.grp_ptr.data_ptr(), cb.ids.data_ptr(), n_groups,
-                                                x.data_ptr(), x.stride(0), self._ranks[slot].data_ptr(), acc[slot].data_ptr(),
+                                                x.data_ptr(), x.stride(0), rk.data_ptr(), acc[slot].data_ptr(),
                                                 self._ws[slot].data_ptr(), self._ws[slot].numel(), sh, sh), "okge_evaluate_batch")
             keep.append(cb)
         for st in self.streams:
             main.wait_stream(st)
         a = acc.sum(0).cpu().tolist()
+        if self.collect_ranks:
+            self.ranks = torch.cat(kept) if kept else torch.zeros(0, dtype=torch.int64, device=self.device)
         del keep
         return _meters(a)

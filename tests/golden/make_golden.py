@@ -39,6 +39,8 @@ Vectors:
                   evaluation slice of the trained tables (scores, per-group ranks, MRR / MR / Hits)
   g12_variant_*   LookupComplexRelationModel with batch_norm / project_entity / normalize='norm' / l2_reg on
                   (model.py:463-479): loss, hook loss, outputs, every parameter's gradient, running stats, eval scores
+  g13_valid_pass  reference-trained tables (rounded to bf16, stored 16-bit) + the reference's evaluation over ALL of
+                  FB15k-237 valid.txt (its loader, collate, eval-mode AddLossModule, compute_metrics): per-group ranks, meters
   g11_traj_*      30 training steps at the BASELINE size on real FB15k-237 batches (reference dataset + collate), then
                   filtered ranks / MRR of the first valid.txt batch on the trained tables
 """
@@ -804,6 +806,93 @@ def g11():
 
 
 # ----------------------------------------------------------------------------------------------
+# G13: a FULL validation pass of the reference over FB15k-237 valid.txt (Trainer.evaluate's arithmetic, every batch)
+# ----------------------------------------------------------------------------------------------
+def g13():
+    """The reference trains LookupComplexRelationModel d=200 (AddLossModule bce, OptimRegime Adagrad lr 0.3 wd 1e-10,
+    input_dropout 0.4) for three passes over its own loader on test.txt (the stand-in training split: train.txt is absent
+    upstream).  The trained tables are then ROUNDED TO bf16-REPRESENTABLE VALUES -- so that both sides can hold exactly
+    the same tables in a 16-bit fixture -- loaded back into the model, and the reference's evaluation runs over ALL of
+    valid.txt exactly as scripts/train.py + Trainer.evaluate do it: dataset.get_loader(shuffle=False, drop_last=False)
+    -> collate -> AddLossModule in eval mode (trainer.py:258-272) -> compute_metrics (dataset.py:423-453), MetricResult
+    summed over the batches.  Stored: the 16-bit tables, the per-group ranks of every batch (reference tensor ops), the
+    per-batch group counts and the final meters."""
+    import shutil
+    import tempfile
+    fb = "/root/reference/data/fb15k237/mapped_to_ids"
+    scratch = tempfile.mkdtemp(prefix="okge_g13_")
+    try:
+        for f in os.listdir(fb):
+            shutil.copy(os.path.join(fb, f), scratch)
+        files = {"train": "test.txt", "valid": "valid.txt", "test": "test.txt"}
+        ds = {}
+        for split in ("train", "valid"):
+            ds[split] = OneToNMentionRelationDataset(dataset_dir=scratch, input_file=files[split],
+                                                     is_training_data=(split == "train"), batch_size=512, copy_data_to_dev_shm=False)
+        for split in ("train", "valid"):
+            ds[split].merge_all_splits_triples(dataset_dir=scratch, train_input_file=files["train"],
+                                               valid_input_file=files["valid"], test_input_file=files["test"])
+            ds[split].create_data_tensors(dataset_dir=scratch, train_input_file=files["train"],
+                                          valid_input_file=files["valid"], test_input_file=files["test"])
+        tr, v = ds["train"], ds["valid"]
+        n_ent, n_rel = v.entity_vocab_size, v.relations_size
+        seed, d = 2026, 200
+        m = make_model("LookupComplexRelationModel", n_ent, n_rel, d, seed=seed, input_dropout=0.4, init_std=0.1)
+        m.train()
+        args = {"optimization_config": {"optimizer": "Adagrad", "epoch": 0, "lr": 0.3, "weight_decay": 1.0e-10},
+                "lr_scheduler_config": None}
+        opts = OptimRegime.setup_optimizer_regime(args=args, model=m)
+        mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+        mod.train()
+        step, losses = 0, []
+        torch.manual_seed(seed + 1)
+        for epoch in range(3):
+            for batch in tr.get_loader(shuffle=True, num_workers=0, drop_last=True):
+                inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = batch
+                step += 1
+                for o in opts:
+                    o.update(epoch + 1, step)
+                    o.zero_grad()
+                loss, _, _ = mod(inputs=list(inputs), labels=labels, use_batch_shared_entities=False,
+                                 batch_shared_entities=cand, epoch=epoch + 1, input_style_triple_or_prefix="right_and_left_prefix")
+                (loss.sum() / float(norm_loss)).backward()
+                for o in opts:
+                    o.step()
+                losses.append(loss.item() / float(norm_loss))
+        print("g13: trained", step, "steps; loss/normalizer", losses[0], "->", losses[-1])
+        # tables both sides can hold exactly: round to bf16, keep the 16 bits
+        with torch.no_grad():
+            Eb, Rb = m.entity_embedding.weight.bfloat16(), m.relation_embedding.weight.bfloat16()
+            m.entity_embedding.weight.copy_(Eb.float())
+            m.relation_embedding.weight.copy_(Rb.float())
+        mod.eval()
+        ranks, groups_per_batch, rows_per_batch, total, loss_sum = [], [], [], None, 0.0
+        with torch.no_grad():
+            for batch in v.get_loader(shuffle=False, num_workers=0, drop_last=False):
+                inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = batch
+                loss, _, outputs = mod(inputs=list(inputs), labels=labels, use_batch_shared_entities=False,
+                                       batch_shared_entities=cand, epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+                res = OneToNMentionRelationDataset.compute_metrics(filter_mask=filt, label_ids=label_ids, predictions=outputs.clone())
+                total = res if total is None else total + res                 # Trainer.compute_one_epoch, trainer.py:310
+                r = per_group_ranks(filt, label_ids, outputs.clone())
+                ranks.append(r)
+                groups_per_batch.append(len(r))
+                rows_per_batch.append(outputs.shape[0])
+                loss_sum += float(loss.item())
+        ranks = np.concatenate(ranks)
+        print("g13: batches", len(groups_per_batch), "groups", len(ranks), "mrr", total["mrr"].avg, "h10", total["h10"].avg)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    save("g13_valid_pass_fb15k237", seed=np.int64(seed), n_ent=np.int64(n_ent), n_rel=np.int64(n_rel), d=np.int64(d),
+         E_bf16=Eb.view(torch.int16).numpy().view(np.uint16).copy(), R_bf16=Rb.view(torch.int16).numpy().view(np.uint16).copy(),
+         batch_size=np.int64(512), ranks=ranks.astype(np.int32), groups_per_batch=np.asarray(groups_per_batch, np.int64),
+         rows_per_batch=np.asarray(rows_per_batch, np.int64), eval_loss_sum=np.float64(loss_sum),
+         train_steps=np.int64(step), train_loss_first=np.float64(losses[0]), train_loss_last=np.float64(losses[-1]),
+         **{"m_" + k: np.float64(val.avg) for k, val in total.items() if k != "loss"},
+         **{"c_" + k: np.float64(val.count) for k, val in total.items() if k != "loss"})
+
+
+# ----------------------------------------------------------------------------------------------
 # G12: embedder variants of the lookup models (batch-norm, entity projection, normalisation, l2_reg hook)
 # ----------------------------------------------------------------------------------------------
 def g12():
@@ -903,7 +992,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)

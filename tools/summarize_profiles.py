@@ -29,18 +29,19 @@ traffic = {}
 for k in sorted(set(fetch) | set(write)):
     if k.startswith("_"):
         continue
-    if not any(x in k for x in ("fused", "dq", "prefix", "adagrad", "encode", "ranks", "eval_")):
+    if not any(x in k for x in ("fused", "dq", "prefix", "adagrad", "encode", "ranks", "eval_", "pool", "bn_", "col_", "dc_reduce")):
         continue
     fk, wk = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
     traffic[k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": 2.0 * fk * 1024 + wk * 1024}
-traffic["_command"] = "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline (OKGE_BENCH_OLP=0)"
+traffic["_command"] = "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- " + os.environ.get(
+    "OKGE_PROFILE_COMMAND", "python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline (OKGE_BENCH_OLP=0)")
 traffic["_commit"] = os.environ.get("OKGE_COMMIT")          # stamped by tools/publish_profiles.py in the build container
 json.dump(traffic, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(root, "pmc_summary.txt"), "w") as out:
     for sub in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
         out.write(f"== {sub}\n")
         for k, d in sorted(pmc(sub).items()):
-            if any(x in k for x in ("fused", "dq", "prefix", "adagrad", "encode", "eval_")):
+            if any(x in k for x in ("fused", "dq", "prefix", "adagrad", "encode", "eval_", "pool", "bn_", "col_", "dc_reduce")):
                 out.write(k + "\n")
                 for c, v in sorted(d.items()):
                     out.write(f"    {c:36s} mean/launch = {v:16.1f}\n")
