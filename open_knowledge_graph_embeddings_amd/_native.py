@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_i
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libokge_hip.so")
-SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_train64.hip", "okge_misc.hip", "okge_pool.hip", "okge_collate.cpp", "okge_dataset.cpp"]
+SOURCES = ["okge_api.hip", "okge_train.hip", "okge_train32.hip", "okge_train64.hip", "okge_train64k.hip", "okge_misc.hip", "okge_pool.hip", "okge_collate.cpp", "okge_dataset.cpp"]
 # every header a source may include: all of csrc/*.h (listed by the directory, so a new header cannot be forgotten) + the ABI
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "okge.h")]
 

@@ -142,6 +142,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct Geometry {
     int    B, N, d, Bpad, D16, KB, LDK, ldq, ldg, tiles, b_split, b_per_block, nsplit;
     int    tile_w, ktiles;      // fused train kernel: tile width (32 or 64 candidates) and tile count
+    int    sk_wgs, sk_chunks;   // > 0: the train tile kernel is launched stream-K shaped over sk_wgs workgroups (okge_train64k.hip)
     bool   dq8;
     // training sweeps the candidates in RANGES of range_n (a multiple of 64) so that the one (B, N)-shaped
     // intermediate, G^T, and everything sized like it (masked rows Cm, KL statistics) is O(B x range_n):
@@ -155,6 +156,21 @@ int env_int(const char *name, int dflt)
 {
     const char *v = std::getenv(name);
     return v && *v ? std::atoi(v) : dflt;
+}
+
+// compute units of the current device (stream-K launches: one workgroup per CU); 256 where no device answers
+int cu_count()
+{
+    static std::mutex mu;
+    static int cus[OKGE_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cus[dev]) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
 }
 
 bool make_geometry(int B, int N, int d, Geometry &g)
@@ -186,8 +202,8 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.ldg = g.range_tiles * NT;
     // fused train kernel: one 8-wave workgroup per CU on 64-candidate tiles (slot sizes up to 256), or the 32-candidate
     // cut for larger slots (an even tile count so that every 64-candidate chunk dq_kernel reads has been written)
-    g.tile_w = g.KB <= 16 ? 64 : 32;
-    g.tile_w = env_int("OKGE_TILE_W", g.tile_w) == 32 ? 32 : g.tile_w;      // diagnostic: the round-1 cut
+    // (slot sizes above 256: fused_tile64k_kernel, candidate tile in registers; OKGE_TILE_W=32 selects the round-1/2 cut)
+    g.tile_w = env_int("OKGE_TILE_W", 64) == 32 ? 32 : 64;
     g.ktiles = g.tiles * (NT / g.tile_w);
     const int slots = (g.tile_w == 64 || g.KB > 16) ? 256 : 512;       // one workgroup per CU, except the 32-wide cut at d <= 256
     // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y.  Cost of a split into c:
@@ -209,6 +225,16 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.b_per_block = (bblks + bs - 1) / bs * BC;
     g.b_split = (g.Bpad + g.b_per_block - 1) / g.b_per_block;
     if (g.n_ranges > 1) { g.b_split = 1; g.b_per_block = g.Bpad; }   // many tiles: no batch split
+    // slot sizes above 256 (fused_tile64k_kernel), one launch: (tile, 32-row chunk) units in equal runs over one workgroup
+    // per CU instead of a (tiles, batch splits) grid -- see the kernel's header for the measurements behind it
+    g.sk_wgs = g.sk_chunks = 0;
+    if (g.KB == 32 && g.tile_w == 64 && g.n_ranges == 1 && env_int("OKGE_STREAMK", 1) != 0 && env_int("OKGE_B_SPLIT", 0) == 0) {
+        g.sk_chunks = (B + 31) / 32;
+        const int64_t units = (int64_t)g.tiles * g.sk_chunks;
+        g.sk_wgs = (int)std::min<int64_t>(std::min(cu_count(), 511), units);
+        g.b_split = 1;
+        g.b_per_block = g.Bpad;
+    }
     // dQ kernel: (batch block, candidate range) workgroups: 8-wave workgroups, one per CU (d <= 256), else 4-wave, two per CU
     g.dq8 = g.KB <= 16 && env_int("OKGE_DQ8", 1) != 0;
     int ns = std::max(1, (g.dq8 ? 256 : 512) / bblks);
@@ -228,11 +254,12 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.off_run = off;   off += align_up((size_t)g.Bpad * 2 * sizeof(float), 256);
     g.lse_bytes = off;
     // [training part]
-    g.off_loss = off;  off += align_up((size_t)2 * g.tiles * g.b_split * sizeof(double), 256);
+    g.off_loss = off;  off += align_up((size_t)std::max(2 * g.tiles * g.b_split, g.sk_wgs) * sizeof(double), 256);
     g.off_GT = off;    off += align_up((size_t)g.Bpad * g.ldg * sizeof(float), 256);
     g.off_Cm = off;    off += align_up((size_t)g.range_tiles * NT * g.D16 * sizeof(float), 256);
     g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
-    g.off_dcs = off;   off += g.b_split > 1 ? align_up((size_t)g.b_split * g.tiles * NT * g.D16 * sizeof(float), 256) : 0;
+    g.off_dcs = off;   off += g.sk_wgs > 0 ? align_up((size_t)2 * g.sk_wgs * NT * g.D16 * sizeof(float), 256)
+                                     : g.b_split > 1 ? align_up((size_t)g.b_split * g.tiles * NT * g.D16 * sizeof(float), 256) : 0;
     g.total = off;
     return true;
 }
@@ -371,7 +398,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     {
         ScopedTimer tm("fused_tile_score", st);
         hipError_t e = g.KB <= 16 ? launch_fused(MODE_SCORE, a, g.tiles, 1, st)        // 64x64 cut
-                                  : launch_fused32(MODE_SCORE, a, g.ktiles, 1, st);    // slot sizes above 256
+                                  : launch_fused32(MODE_SCORE, a, 2 * g.tiles, 1, st);    // slot sizes above 256
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     return OKGE_OK;
@@ -427,7 +454,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     a.G = reinterpret_cast<float *>(ws + g.off_GT);
     a.Cm = reinterpret_cast<float *>(ws + g.off_Cm);
     a.dE = dE;
-    a.dC_slab = g.b_split > 1 ? reinterpret_cast<float *>(ws + g.off_dcs) : nullptr;
+    a.dC_slab = (g.b_split > 1 || g.sk_wgs > 0) ? reinterpret_cast<float *>(ws + g.off_dcs) : nullptr;
     a.loss_partial = reinterpret_cast<double *>(ws + g.off_loss);
     a.loss_kind = loss_kind;
     a.inv_norm = (float)(1.0 / normalizer);
@@ -444,7 +471,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         s.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
         s.b_per_block = g.Bpad;
         ScopedTimer tm("fused_tile_score", st);
-        e = g.KB <= 16 ? launch_fused(MODE_SCORE, s, g.tiles, 1, st) : launch_fused32(MODE_SCORE, s, g.ktiles, 1, st);
+        e = g.KB <= 16 ? launch_fused(MODE_SCORE, s, g.tiles, 1, st) : launch_fused32(MODE_SCORE, s, 2 * g.tiles, 1, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     if (loss_kind == OKGE_LOSS_KL) {
@@ -469,16 +496,28 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     q.nsplit = g.nsplit;
     q.waves8 = g.dq8 ? 1 : 0;
     const int mode = loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE;
+    const int n_loss_partials = g.sk_wgs > 0 ? g.sk_wgs : g.ktiles * g.b_split;
     for (int r = 0; r < g.n_ranges; ++r) {
         int tiles_r;
         const FusedArgs ar = range_args(a, g, r, tiles_r);
         {
             ScopedTimer tm("fused_tile_train", st);
-            e = g.tile_w == 64 ? launch_fused64(mode, ar, tiles_r, g.b_split, st) : launch_fused32(mode, ar, 2 * tiles_r, g.b_split, st);
+            if (g.sk_wgs > 0) {                     // stream-K: a.sk_tiles tiles x sk_chunks chunks over sk_wgs workgroups
+                FusedArgs as = ar;
+                as.sk_tiles = tiles_r;
+                e = launch_fused64(mode, as, g.sk_wgs, 1, st);
+            } else {
+                e = g.tile_w == 64 ? launch_fused64(mode, ar, tiles_r, g.b_split, st) : launch_fused32(mode, ar, 2 * tiles_r, g.b_split, st);
+            }
             if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
         }
         if (loss_only) continue;
-        if (g.b_split > 1) {                        // (few candidate tiles: always a single range)
+        if (g.sk_wgs > 0) {
+            ScopedTimer tm("dc_reduce", st);
+            e = launch_dc_reduce_streamk(a.dC_slab, tiles_r, g.sk_chunks, g.sk_wgs, g.D16, ar.N, g.d, cand->ids, cand->first_id,
+                                         a.cand_exclusive, a.grads_zero, dE, a.n_table_rows, a.id_err, st);
+            if (e != hipSuccess) return fail_hip(e, "dc_reduce_streamk");
+        } else if (g.b_split > 1) {                 // (few candidate tiles: always a single range)
             ScopedTimer tm("dc_reduce", st);
             e = launch_dc_reduce(a.dC_slab, g.b_split, g.tiles * NT, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
                                  a.grads_zero, dE, a.n_table_rows, a.id_err, st);
@@ -492,13 +531,13 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     }
     if (loss_only) {
         ScopedTimer tm("loss_reduce", st);
-        e = launch_loss_reduce(a.loss_partial, g.ktiles * g.b_split, loss_out, st);
+        e = launch_loss_reduce(a.loss_partial, n_loss_partials, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "loss_reduce");
         return OKGE_OK;
     }
     if (dq_out) {
         ScopedTimer tm("slab_reduce", st);          // + the deterministic loss reduction (one extra workgroup)
-        e = launch_slab_reduce(q.slab, g.nsplit, (int64_t)g.Bpad * g.ldq, dq_out, a.loss_partial, g.ktiles * g.b_split,
+        e = launch_slab_reduce(q.slab, g.nsplit, (int64_t)g.Bpad * g.ldq, dq_out, a.loss_partial, n_loss_partials,
                                loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "slab_reduce");
         return OKGE_OK;
@@ -507,7 +546,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         ScopedTimer tm("prefix_backward", st);      // + the deterministic loss reduction (one extra workgroup)
         const PrefixDev p = to_dev(*batch, t, sh);
         e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, nullptr, dE, dR,
-                                   a.loss_partial, g.ktiles * g.b_split, loss_out, st);
+                                   a.loss_partial, n_loss_partials, loss_out, st);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
     }
     return OKGE_OK;
@@ -626,7 +665,7 @@ int okge_score_queries(const okge_tables *t, const okge_shard *sh, const float *
     a.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
     a.b_per_block = g.Bpad;
     ScopedTimer tm("fused_tile_score", st);
-    hipError_t e = g.KB <= 16 ? launch_fused(MODE_SCORE, a, g.tiles, 1, st) : launch_fused32(MODE_SCORE, a, g.ktiles, 1, st);
+    hipError_t e = g.KB <= 16 ? launch_fused(MODE_SCORE, a, g.tiles, 1, st) : launch_fused32(MODE_SCORE, a, 2 * g.tiles, 1, st);
     if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     return OKGE_OK;
 }

@@ -67,6 +67,7 @@ struct FusedArgs {
     int64_t        n_table_rows;   // rows of the table `E` points to: candidate ids are checked against it (checked_row)
     int           *id_err;         // device word counting out-of-range ids
     int32_t        loss_only;  // forward + loss only: no G store, no dC product, no write-back
+    int32_t        sk_tiles;   // fused_tile64k_kernel: > 0 = stream-K launch over this many candidate tiles (grid = workgroups)
 };
 
 struct DqArgs {
@@ -94,6 +95,7 @@ hipError_t launch_fused(int mode, const FusedArgs &a, int grid_x, int grid_y, hi
 hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st);
 hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 hipError_t launch_fused64(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
+hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);   // slot sizes above 256
 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
@@ -140,6 +142,11 @@ hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, in
 hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
                             int cand_first, int exclusive, int grads_zero, float *dE, int64_t table_rows, int *id_err,
                             hipStream_t st);
+// sums the partial candidate-gradient slabs of a stream-K launch of fused_tile64k_kernel (slab 2p / 2p+1 = first / last
+// segment of workgroup p; tiles covered by one whole segment were stored by the tile kernel itself)
+hipError_t launch_dc_reduce_streamk(const float *slab, int tiles, int chunks_per_tile, int workgroups, int D16, int N, int d,
+                                    const int32_t *cand_ids, int cand_first, int exclusive, int grads_zero, float *dE,
+                                    int64_t table_rows, int *id_err, hipStream_t st);
 hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, int64_t ldr, const float *O, int64_t ldo,
                                 int n, int d, int scorer, float *out, hipStream_t st);
 hipError_t launch_rank_metrics(const int64_t *ranks, int64_t n, double *acc, hipStream_t st);

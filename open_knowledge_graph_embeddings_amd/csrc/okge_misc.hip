@@ -183,6 +183,60 @@ __global__ __launch_bounds__(256) void dc_reduce_kernel(const float *__restrict_
     }
 }
 
+// Stream-K launches of fused_tile64k_kernel (okge_train64k.hip): the (tile, chunk) units, tile-major, are cut into `P` equal
+// runs; workgroup p owns units [U p / P, U (p + 1) / P), U = tiles * J.  A tile covered by ONE segment was written by that
+// workgroup; otherwise every segment left its partial rows in slab 2 p (p's run starts inside the tile) or 2 p + 1 (it
+// ends there).  One workgroup per tile: list the slabs (in p order: the sum is reproducible), add them, store / accumulate.
+__global__ __launch_bounds__(256) void dc_reduce_streamk_kernel(const float *__restrict__ slab, int tiles, int J, int P, int D16,
+                                                                int N, int d, const int32_t *__restrict__ cand_ids,
+                                                                int cand_first, int exclusive, int grads_zero,
+                                                                float *__restrict__ dE, int64_t table_rows,
+                                                                int *__restrict__ id_err)
+{
+    // grid: 8 workgroups per tile (8 candidate rows each: the launch is a 3 x 20 MB stream, it needs the whole chip)
+    __shared__ int slots[1024];
+    __shared__ int n_slots;
+    const int t = blockIdx.x >> 3, r0 = 8 * (blockIdx.x & 7);
+    const int64_t U = (int64_t)tiles * J, lo = (int64_t)t * J, hi = lo + J;
+    if (threadIdx.x == 0) {
+        int64_t p = lo * P / U;
+        while (p > 0 && U * p / P > lo) --p;
+        while (U * (p + 1) / P <= lo) ++p;
+        int cnt = 0;
+        bool whole = false;
+        for (; p < P && U * p / P < hi; ++p) {
+            const int64_t ub = U * p / P, ue = U * (p + 1) / P;
+            const int64_t j0 = (ub > lo ? ub : lo) - lo, j1 = (ue < hi ? ue : hi) - lo;
+            if (j1 <= j0) continue;
+            if (j0 == 0 && j1 == J) { whole = true; break; }
+            if (cnt < 1024) slots[cnt++] = (int)(2 * p + (ub >= lo ? 0 : 1));
+        }
+        n_slots = whole ? 0 : cnt;
+    }
+    __syncthreads();
+    const int ns = n_slots;
+    if (ns == 0) return;
+    const int q4 = D16 >> 2;
+    for (int i = threadIdx.x; i < 8 * q4; i += 256) {
+        const int r = r0 + i / q4, k = 4 * (i % q4), n = 64 * t + r;
+        if (n >= N || k >= d) continue;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < ns; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(slab + ((size_t)slots[j] * 64 + r) * D16 + k);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        const int64_t cid = checked_row(cand_ids ? (int64_t)cand_ids[n] : (int64_t)cand_first + n, table_rows, k ? nullptr : id_err);
+        float *dst = dE + cid * d + k;
+        const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (k + e >= d) break;
+            if (!exclusive) atomicAdd(dst + e, v[e]);
+            else dst[e] = grads_zero ? v[e] : dst[e] + v[e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                               int d, int scorer, const PrefixDev p,
                                                               const float *__restrict__ slab, int nsplit, int Bpad,
@@ -846,6 +900,17 @@ hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(dc_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, nsplit, rows_pad, D16, N,
                        d, cand_ids, cand_first, exclusive, grads_zero, dE, table_rows, id_err);
+    return hipGetLastError();
+}
+
+hipError_t launch_dc_reduce_streamk(const float *slab, int tiles, int chunks_per_tile, int workgroups, int D16, int N, int d,
+                                    const int32_t *cand_ids, int cand_first, int exclusive, int grads_zero, float *dE,
+                                    int64_t table_rows, int *id_err, hipStream_t st)
+{
+    if (tiles <= 0) return hipSuccess;
+    if (workgroups > 511) return hipErrorInvalidValue;             // (slot list of a tile: at most workgroups + 1 entries)
+    hipLaunchKernelGGL(dc_reduce_streamk_kernel, dim3(8 * tiles), dim3(256), 0, st, slab, tiles, chunks_per_tile, workgroups, D16,
+                       N, d, cand_ids, cand_first, exclusive, grads_zero, dE, table_rows, id_err);
     return hipGetLastError();
 }
 
