@@ -394,14 +394,27 @@ int okge_evaluate_fused(const okge_tables *t, const okge_prefix_batch *batch, co
                         const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
                         const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
                         void *workspace, size_t workspace_bytes, void *stream);
-/* The three launches of okge_evaluate_fused one at a time (phase 1 = queries + point scores, 2 = tile sweep, 4 = ranks +
- * meters; same arguments, same workspace), so that a caller can put the two small latency-bound kernels of neighbouring
- * batches on another stream beside the sweep.  The CALLER orders 1 -> 2 -> 4 of one batch (stream order or events) and
- * gives every batch in flight its own workspace and ranks buffer. */
-int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
-                              const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
-                              const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
-                              void *workspace, size_t workspace_bytes, void *stream);
+/* CANDIDATE-SHARDED fused evaluation (entity table row-sharded over the GPUs of a node, SURVEY.md section 8e: exact ranks need
+ * integer counts summed over the shards, not a per-shard top-k): the three launches of okge_evaluate_fused one at a time, on
+ * THIS rank's candidates, with the two exchanges between them left to the caller (RCCL):
+ *   phase 1  point scores.  The queries arrive FOLDED in `Q` ([B][ldq], okge_fold_queries on the exchanged entity rows).
+ *            `cand` = the local candidates (rows of the local table `t`); they are the global candidate columns
+ *            sh->cand_col0 .. + cand->n - 1 of n_cand_global.  ids / filt_col hold GLOBAL columns, identical on every rank.
+ *            true_scores[g] (the sweep's sorted group numbering, same on every rank) = max over the group's ids THIS rank
+ *            holds, -inf if none;                      -> caller: all-reduce(MAX) over the ranks
+ *   phase 2  the tile sweep over the local candidates against the (global) true scores
+ *   phase 4  counts[g] = {#greater, #equal} of this rank: sweep counts + the filter correction of the filter columns it
+ *            holds (original group numbering);          -> caller: all-reduce(SUM); rank = #greater + #equal / 2
+ * Point scores use the tile kernel's summation order, every candidate is scored on exactly one rank: the summed counts,
+ * hence the ranks, are bit-equal to okge_evaluate_fused on the unsharded table (tests/test_sharded.py).
+ * Replaces dataset.py:423-453 for sharded tables without the (B, N / world) score block (5.1 GB per rank and batch at the
+ * 2.5 M-entity shape).  Same workspace as okge_evaluate_fused (okge_eval_workspace_bytes with the LOCAL candidate count); the
+ * caller orders 1 -> 2 -> 4 of a batch.  Slot sizes up to 256, eval mode. */
+int okge_evaluate_fused_shard(int32_t phase, const okge_tables *t, const okge_shard *sh, const float *Q, int64_t ldq, int32_t B,
+                              const okge_candidates *cand, int32_t n_cand_global, const int64_t *filt_ptr, const int32_t *filt_col,
+                              int64_t n_filter, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
+                              int64_t n_groups, float *true_scores, int64_t *counts, void *workspace, size_t workspace_bytes,
+                              void *stream);
 /* A RUN of evaluation batches in one host call: Trainer.evaluate's loop (trainer.py:363-369) over n_batches batches.
  * Batch i runs on streams[i % n_streams] (1 to 4 different streams); each stream is an independent chain with two launches
  * per batch -- [points i] [sweep i] [ranks i + points i+S] [sweep i+S] ... (the ranks + meters of a batch and the point

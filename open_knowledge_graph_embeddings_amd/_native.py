@@ -30,7 +30,7 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_score_workspace_bytes", "okge_lse_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
-           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_phase", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
+           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_shard", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
            "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
            "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
@@ -225,8 +225,10 @@ def lib():
     L.okge_evaluate_fused.restype = c_int32
     L.okge_evaluate_fused.argtypes = [POINTER(Tables), POINTER(PrefixBatch), POINTER(Candidates), c_void_p, c_void_p, c_int64,
                                       c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
-    L.okge_evaluate_fused_phase.restype = c_int32
-    L.okge_evaluate_fused_phase.argtypes = [c_int32] + L.okge_evaluate_fused.argtypes
+    L.okge_evaluate_fused_shard.restype = c_int32
+    L.okge_evaluate_fused_shard.argtypes = [c_int32, POINTER(Tables), POINTER(Shard), c_void_p, c_int64, c_int32, POINTER(Candidates),
+                                            c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                            c_void_p, c_void_p, c_size_t, c_void_p]
     L.okge_evaluate_fused_batches.restype = c_int32
     L.okge_evaluate_fused_batches.argtypes = [POINTER(Tables), POINTER(EvalBatch), c_int32, c_void_p, c_void_p, c_void_p,
                                               c_size_t, POINTER(c_void_p), c_int32]

@@ -980,34 +980,55 @@ struct EvalCall {                      // one batch's launch arguments, built on
 };
 }  // namespace
 
+// Candidate-sharded call (okge_evaluate_fused_shard): folded queries from outside, the shard's candidate columns, the
+// true scores in a caller-owned buffer (they are exchanged between the phases), counts instead of ranks.
+struct EvalShard {
+    const float *Q_in;
+    int32_t      B, col_lo, n_cand_global;
+    float       *true_scores;
+    int64_t     *counts_out;
+};
+
 static int eval_call(EvalCall &c, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
                      const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
                      const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
-                     void *workspace, size_t workspace_bytes)
+                     void *workspace, size_t workspace_bytes, const EvalShard *es = nullptr)
 {
-    if (int rc = check_common(t, batch, cand)) return rc;
-    if (!filt_ptr || !row_ptr || !grp_ptr || (n_groups > 0 && !ids) || !ranks || !acc || n_groups < 0 || n_filter < 0 ||
+    if (!es) {
+        if (int rc = check_common(t, batch, cand)) return rc;
+    }
+    if (!filt_ptr || !row_ptr || !grp_ptr || (n_groups > 0 && !ids) || (!es && (!ranks || !acc)) || n_groups < 0 || n_filter < 0 ||
         (n_filter > 0 && !filt_col))                      // (a batch without answer groups has no ids array)
         return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
     if (t->d > 256) return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation covers slot sizes up to 256: use okge_evaluate_batch");
-    if (cand->table || cand->drop.p > 0.f || batch->drop_po_ent.p > 0.f || batch->drop_sp_ent.p > 0.f ||
-        batch->drop_po_rel.p > 0.f || batch->drop_sp_rel.p > 0.f)
+    if (cand->table || cand->drop.p > 0.f || (batch && (batch->drop_po_ent.p > 0.f || batch->drop_sp_ent.p > 0.f ||
+        batch->drop_po_rel.p > 0.f || batch->drop_sp_rel.p > 0.f)))
         return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation is the eval-mode path (no dropout, candidates from the entity table)");
     c.n_groups = n_groups;
     if (n_groups == 0) return OKGE_OK;
-    const int32_t B = batch->n_po + batch->n_sp;
+    const int32_t B = es ? es->B : batch->n_po + batch->n_sp;
     Geometry &g = c.g;
     EvalGeometry &eg = c.eg;
     eval_geometry(B, cand->n, t->d, n_groups, n_filter, g, eg);
     if (!workspace || workspace_bytes < eg.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
     char *ws = static_cast<char *>(workspace);
-    float *Q = reinterpret_cast<float *>(ws + eg.off_Q), *tru = reinterpret_cast<float *>(ws + eg.off_true);
+    float *Q = reinterpret_cast<float *>(ws + eg.off_Q), *tru = es ? es->true_scores : reinterpret_cast<float *>(ws + eg.off_true);
     float *fx = reinterpret_cast<float *>(ws + eg.off_filt);
     c.counts = reinterpret_cast<int32_t *>(ws + eg.off_counts);
     int64_t *rps = reinterpret_cast<int64_t *>(ws + eg.off_rps), *gshift = reinterpret_cast<int64_t *>(ws + eg.off_gshift);
     int32_t *grow = reinterpret_cast<int32_t *>(ws + eg.off_grow);
     EvalPointsArgs &p = c.pts;
-    p.E = t->E; p.R = t->R; p.p = to_dev(*batch, t); p.Q = Q; p.cand_ids = cand->ids;
+    p.E = t->E; p.R = t->R; p.Q = Q; p.cand_ids = cand->ids;
+    if (es) {                                             // rows come folded: no prefix ids here, only their number
+        std::memset(&p.p, 0, sizeof(p.p));
+        p.p.n_po = B;
+        p.p.id_err = id_err_ptr();
+    } else {
+        p.p = to_dev(*batch, t);
+    }
+    p.Q_in = es ? es->Q_in : nullptr;
+    p.col_lo = es ? es->col_lo : 0;
+    p.n_cand_global = es ? es->n_cand_global : cand->n;
     p.row_ptr = row_ptr; p.grp_ptr = grp_ptr; p.filt_ptr = filt_ptr; p.ids = ids; p.filt_col = filt_col;
     p.true_out = tru; p.filt_x = fx; p.row_ptr_sorted = rps; p.gshift = gshift; p.group_row = grow;
     p.table_rows = t->n_ent; p.d = t->d; p.scorer = t->scorer; p.ldq = g.ldq; p.KB = g.KB; p.Bpad = g.Bpad;
@@ -1022,6 +1043,7 @@ static int eval_call(EvalCall &c, const okge_tables *t, const okge_prefix_batch 
     EvalRanksArgs &r = c.rk;
     r.counts = a.rk_counts; r.slab = a.rk_slab; r.true_scores = tru; r.filt_x = fx; r.filt_ptr = filt_ptr; r.gshift = gshift;
     r.group_row = grow; r.ranks = ranks; r.acc = acc; r.n_groups = n_groups; r.tiles = g.tiles; r.B = B;
+    r.counts_out = es ? es->counts_out : nullptr;
     return OKGE_OK;
 }
 
@@ -1072,14 +1094,29 @@ int okge_evaluate_fused(const okge_tables *t, const okge_prefix_batch *batch, co
                                workspace, workspace_bytes, stream);
 }
 
-int okge_evaluate_fused_phase(int32_t phase, const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,
-                              const int64_t *filt_ptr, const int32_t *filt_col, int64_t n_filter, const int64_t *row_ptr,
-                              const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, int64_t *ranks, double *acc,
-                              void *workspace, size_t workspace_bytes, void *stream)
+int okge_evaluate_fused_shard(int32_t phase, const okge_tables *t, const okge_shard *sh, const float *Q, int64_t ldq, int32_t B,
+                              const okge_candidates *cand, int32_t n_cand_global, const int64_t *filt_ptr, const int32_t *filt_col,
+                              int64_t n_filter, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
+                              int64_t n_groups, float *true_scores, int64_t *counts, void *workspace, size_t workspace_bytes,
+                              void *stream)
 {
-    if (phase != 1 && phase != 2 && phase != 4) return fail(OKGE_ERR_INVALID, "phase must be 1 (points), 2 (sweep) or 4 (ranks)");
-    return evaluate_fused_impl(phase, t, batch, cand, filt_ptr, filt_col, n_filter, row_ptr, grp_ptr, ids, n_groups, ranks, acc,
-                               workspace, workspace_bytes, stream);
+    if (phase != 1 && phase != 2 && phase != 4) return fail(OKGE_ERR_INVALID, "phase must be 1 (points), 2 (sweep) or 4 (counts)");
+    if (!t || !t->E || !t->R || t->d <= 0 || t->n_ent <= 0 || !cand || cand->n <= 0 || B <= 0 || !Q || !true_scores || !counts)
+        return fail(OKGE_ERR_INVALID, "bad sharded evaluate arguments");
+    if (int rc = check_shard(t, sh)) return rc;
+    if (ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "query block leading dimension must be okge_query_ld(d)");
+    if (sh->cand_col0 < 0 || (int64_t)sh->cand_col0 + cand->n > n_cand_global)
+        return fail(OKGE_ERR_INVALID, "the shard's candidate columns must lie inside the global candidate list");
+    if (!cand->ids && (cand->first_id < 0 || (int64_t)cand->first_id + cand->n > t->n_ent))
+        return fail(OKGE_ERR_INVALID, "candidate range outside the local entity table");
+    EvalShard es;
+    es.Q_in = Q; es.B = B; es.col_lo = sh->cand_col0; es.n_cand_global = n_cand_global;
+    es.true_scores = true_scores; es.counts_out = counts;
+    EvalCall c;
+    if (int rc = eval_call(c, t, nullptr, cand, filt_ptr, filt_col, n_filter, row_ptr, grp_ptr, ids, n_groups, nullptr, nullptr,
+                           workspace, workspace_bytes, &es))
+        return rc;
+    return eval_issue(phase, c, reinterpret_cast<hipStream_t>(stream));
 }
 
 // events of okge_evaluate_fused_batches (fork / join of the extra streams): one set per device, created on first use on that

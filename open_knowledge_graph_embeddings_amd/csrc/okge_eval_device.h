@@ -116,7 +116,7 @@ __device__ __forceinline__ void eval_points_block(const EvalPointsArgs &a, int b
     rs.owned = false; rs.sp = false; rs.ent = rs.rel = 0; rs.pos = 0;
     int64_t g_lo = 0, g_hi = 0, f_lo = 0, f_hi = 0;
     if (in) {
-        rs = row_source(p, b);
+        if (!a.Q_in) rs = row_source(p, b);
         g_lo = a.row_ptr[b]; g_hi = a.row_ptr[b + 1];
         f_lo = a.filt_ptr[b]; f_hi = a.filt_ptr[b + 1];
     }
@@ -160,6 +160,8 @@ __device__ __forceinline__ void eval_points_block(const EvalPointsArgs &a, int b
         if (cplx) fold_complex(rs.sp, ea, eb, ra, rb, qs[tid], qs[h + tid]);
         else qs[tid] = __fmul_rn(ea, ra);
     }
+    if (a.Q_in && in)                    // sharded: the row was folded from the exchanged entity rows (okge_fold_queries)
+        for (int k = tid; k < 16 * KB; k += nthr) qs[k] = a.Q_in[(size_t)b * ldq + k];
     if (in) {
         pos = red_pos[0] + red_pos[1] + red_pos[2] + red_pos[3];
         start = red_start[0] + red_start[1] + red_start[2] + red_start[3];
@@ -174,20 +176,29 @@ __device__ __forceinline__ void eval_points_block(const EvalPointsArgs &a, int b
     if (!in) return;
     // ---- stage D
     const bool vec_ok = (d & 3) == 0;
-    auto cand_row = [&](int col) {            // col: a position in the candidate list (checked), then an entity row (checked)
-        col = (int)checked_row(col, a.n_cand, p.id_err);
-        const int64_t cid = checked_row(a.cand_ids ? (int64_t)a.cand_ids[col] : (int64_t)a.cand_first + col, a.table_rows, p.id_err);
+    // col: a position in the (global) candidate list (checked); candidates of another shard have no row here (nullptr:
+    // their point scores are that shard's business); then an entity row (checked)
+    auto cand_row = [&](int col) -> const float * {
+        col = (int)checked_row(col, a.n_cand_global, p.id_err);
+        const int loc = col - a.col_lo;
+        if (loc < 0 || loc >= a.n_cand) return nullptr;
+        const int64_t cid = checked_row(a.cand_ids ? (int64_t)a.cand_ids[loc] : (int64_t)a.cand_first + loc, a.table_rows, p.id_err);
         return a.E + cid * d;
     };
     for (int64_t g = g0; g < g_hi; g += nthr) {
-        float t = -INFINITY;
+        float t = -INFINITY;                                 // (sharded: the maximum over THIS shard's ids; -inf if it has none)
         const int64_t lo = g == g0 ? j_lo : a.grp_ptr[g], hi = g == g0 ? j_hi : a.grp_ptr[g + 1];
-        for (int64_t j = lo; j < hi; ++j) t = fmaxf(t, point_score(qs, cand_row(g == g0 && j == lo ? id0 : a.ids[j]), d, KB, vec_ok));
+        for (int64_t j = lo; j < hi; ++j) {
+            const float *row = cand_row(g == g0 && j == lo ? id0 : a.ids[j]);
+            if (row) t = fmaxf(t, point_score(qs, row, d, KB, vec_ok));
+        }
         a.true_out[g + (start - g_lo)] = t;                  // sorted group index
         a.group_row[g] = b;
     }
-    for (int64_t f = f0; f < f_hi; f += nthr)
-        a.filt_x[f] = point_score(qs, cand_row(f == f0 ? fcol0 : a.filt_col[f]), d, KB, vec_ok);
+    for (int64_t f = f0; f < f_hi; f += nthr) {
+        const float *row = cand_row(f == f0 ? fcol0 : a.filt_col[f]);
+        a.filt_x[f] = row ? point_score(qs, row, d, KB, vec_ok) : __builtin_nanf("");      // NaN: not this shard's column
+    }
 }
 
 // One wave per answer group: rank = #greater + #equal / 2 from the sweep's counts, after replacing the scores under the
@@ -207,8 +218,10 @@ __device__ __forceinline__ void eval_ranks_block(const EvalRanksArgs &a, int blk
         int gt = 0, eq = 0;
         for (int64_t f = f_lo + lane; f < f_hi; f += 64) {
             const float x = a.filt_x[f];
-            gt += (-1e8f > t) - (x > t);
-            eq += (-1e8f == t) - (x == t);
+            if (x == x) {                                // (NaN: a filter column of another shard, corrected there)
+                gt += (-1e8f > t) - (x > t);
+                eq += (-1e8f == t) - (x == t);
+            }
         }
         if (a.slab)                                      // the sweep's per-tile packed counts of this group
             for (int tl = lane; tl < a.tiles; tl += 64) {
@@ -218,7 +231,10 @@ __device__ __forceinline__ void eval_ranks_block(const EvalRanksArgs &a, int blk
             }
         gt = wave_sum(gt);
         eq = wave_sum(eq);
-        if (lane == 0) {
+        if (lane == 0 && a.counts_out) {                 // sharded: this shard's counts; the caller adds the shards up
+            a.counts_out[2 * g] = (int64_t)(a.slab ? 0 : a.counts[2 * gs]) + gt;
+            a.counts_out[2 * g + 1] = (int64_t)(a.slab ? 0 : a.counts[2 * gs + 1]) + eq;
+        } else if (lane == 0) {
             const int64_t r = (int64_t)(a.slab ? 0 : a.counts[2 * gs]) + gt + ((int64_t)(a.slab ? 0 : a.counts[2 * gs + 1]) + eq) / 2;
             a.ranks[g] = r;
             v[0] = 1.0;

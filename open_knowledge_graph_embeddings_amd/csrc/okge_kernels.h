@@ -164,6 +164,10 @@ struct EvalPointsArgs {
     int32_t       *group_row;              // [n_groups] row of every group (original numbering), for eval_ranks
     int64_t        table_rows;
     int32_t        d, scorer, ldq, KB, Bpad, cand_first, n_cand;
+    // candidate-sharded evaluation (okge_evaluate_fused_shard): the queries arrive folded (original row order), the local
+    // candidates are the global columns col_lo .. col_lo + n_cand - 1 of n_cand_global; ids / filter columns stay global
+    const float   *Q_in;                   // [B][ldq] or nullptr (fold from E / R: the single-device path)
+    int32_t        col_lo, n_cand_global;
 };
 struct EvalRanksArgs {
     const int32_t  *counts;                // [n_groups][2] (atomics path) or nullptr
@@ -173,6 +177,7 @@ struct EvalRanksArgs {
     const int32_t  *group_row;
     int64_t        *ranks;
     double         *acc;
+    int64_t        *counts_out;            // sharded: [n_groups][2] {#greater, #equal} of THIS shard instead of ranks + meters
     int64_t         n_groups;
     int32_t         tiles, B;
 };

@@ -68,9 +68,16 @@ template <int KB> struct Tile64Cfg {
 // chunk buffer: chunk i+1 is parked while chunk i is being worked on, so a chunk has ONE barrier and no staging phase
 // (with one buffer every wave parks, requests and waits between two barriers while the MFMA pipes idle: ~1.3 K of a
 // chunk's 17.9 K cycles), and the score product reads a third less from LDS.
-template <int KB, int MODE, bool REGC>
+// SHORTK (with REGC; the launcher picks it for slot sizes 193..200 at KB = 13, i.e. the d = 200 of BASELINE configs[1]): the
+// contraction needs only 200 of the 208 padded columns.  In the normal k order MFMA j of a round takes the columns
+// 16 r + 4 s + j of lane slot s, so all four MFMAs of the last round touch a padding column; here the LAST round is fed in the
+// order 16 r + 4 j + s (two ds_read_b32 per block instead of one ds_read_b128, the candidate operand read that way once in
+// the prologue), which puts columns 200..207 into MFMAs 2 and 3 -- and those are not issued: 50 instead of 52 score MFMAs
+// per block.  (The gradient product still writes all 208 columns: its OUTPUT is padded, not its contraction.)
+template <int KB, int MODE, bool REGC, bool SHORTK = false>
 __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const FusedArgs a)
 {
+    static_assert(!SHORTK || (REGC && KB >= 3), "the short last round comes with the register-resident candidate operand");
 #ifdef OKGE_STAMPS
     unsigned long long wg_t0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0)::"memory");
@@ -214,6 +221,10 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
     if (REGC) {
 #pragma unroll
         for (int r = 0; r < KB; ++r) breg[r] = *reinterpret_cast<const v4f *>(Cs + (16 * blk + c) * LDK + 16 * r + 4 * s);
+        if (SHORTK) {                   // last round in the order 16 r + 4 j + s, j = 0, 1
+            breg[KB - 1][0] = Cs[(16 * blk + c) * LDK + 16 * (KB - 1) + s];
+            breg[KB - 1][1] = Cs[(16 * blk + c) * LDK + 16 * (KB - 1) + 4 + s];
+        }
         cm_done = NOIT;                 // (written in the prologue)
 #pragma unroll
         for (int it = 0; it < NQIT; ++it) {
@@ -287,20 +298,33 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
 #pragma unroll
             for (int r = 0; r < KB; ++r) {
                 v4f a20 = a10, a21 = a11, b2v = b1v;
+                const bool short_next = SHORTK && r + 2 == KB - 1;          // the round being requested is the short one
                 if (r + 2 < KB) {
-                    a20 = *reinterpret_cast<const v4f *>(qa0 + 16 * (r + 2));
-                    a21 = *reinterpret_cast<const v4f *>(qa1 + 16 * (r + 2));
+                    if (short_next) {
+                        const float *q0 = Qc + (32 * h + c) * LDK + 16 * (KB - 1) + s, *q1 = q0 + 16 * LDK;
+                        a20[0] = q0[0]; a20[1] = q0[4];
+                        a21[0] = q1[0]; a21[1] = q1[4];
+                    } else {
+                        a20 = *reinterpret_cast<const v4f *>(qa0 + 16 * (r + 2));
+                        a21 = *reinterpret_cast<const v4f *>(qa1 + 16 * (r + 2));
+                    }
                     b2v = REGC ? breg[r + 2 < KB ? r + 2 : 0] : *reinterpret_cast<const v4f *>(cb + 16 * (r + 2));
                 }
+                constexpr int NJ_FULL = 4;
+                const int nj = (SHORTK && r == KB - 1) ? 2 : NJ_FULL;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    x0 = mfma16(a00[j], b0v[j], x0);
-                    x1 = mfma16(a01[j], b0v[j], x1);
+                    if (j < nj) {
+                        x0 = mfma16(a00[j], b0v[j], x0);
+                        x1 = mfma16(a01[j], b0v[j], x1);
+                    }
                 }
                 a00 = a10; a01 = a11; b0v = b1v;
                 a10 = a20; a11 = a21; b1v = b2v;
-                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0); // ds_reads of round r+2
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA   (round r)
+                if (short_next) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // ds_reads of round r+2
+                else __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                if (nj == 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // the MFMAs of round r
+                else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
         }
 
@@ -536,7 +560,11 @@ static hipError_t launch64_t(const FusedArgs &a, dim3 grid, hipStream_t st)
 {
     // candidate operand in registers + two query chunk buffers: 4 KB more registers per lane, so slot sizes up to 208
     static const bool regc_on = [] { const char *e = getenv("OKGE_TILE64_REGC"); return !e || atoi(e) != 0; }();
+    static const bool shortk_on = [] { const char *e = getenv("OKGE_TILE64_SHORTK"); return !e || atoi(e) != 0; }();
     auto k = KB <= 13 && regc_on ? fused_tile64_kernel<KB, MODE, (KB <= 13)> : fused_tile64_kernel<KB, MODE, false>;
+    // slot sizes 16 (KB - 1) + 1 .. + 8: the last contraction round needs two of its four MFMAs
+    if (KB == 13 && regc_on && shortk_on && a.d > 16 * (KB - 1) && a.d <= 16 * (KB - 1) + 8)
+        k = fused_tile64_kernel<KB, MODE, (KB == 13), (KB == 13)>;
     const size_t shmem = shmem64<KB>();
     static LdsOptIn lds_opt_in;
     if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(k), shmem); e != hipSuccess) return e;

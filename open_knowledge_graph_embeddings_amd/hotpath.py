@@ -468,6 +468,27 @@ class HotPath:
         del keep
         return ranks[:n_groups], acc
 
+    def evaluate_fused_shard(self, phase, E_local, R, scorer, Q, B, batch: PrefixBatch, shard: "Shard", n_cand_global, filt_ptr,
+                             filt_col, row_ptr, grp_ptr, ids, true_scores, counts):
+        """one launch of the candidate-sharded fused evaluation (okge_evaluate_fused_shard): phase 1 point scores ->
+        true_scores (local maxima), 2 tile sweep, 4 counts; `batch` carries the LOCAL candidate range / list"""
+        c = N.Candidates()
+        cid = _i32(batch.cand_ids, self.device)
+        c.ids, c.first_id, c.n = _ptr(cid), int(batch.cand_first), int(batch.n_candidates)
+        t = self._tables(E_local, R, scorer)
+        n_groups, n_filter = int(grp_ptr.numel()) - 1, int(filt_col.numel())
+        need = int(self.lib.okge_eval_workspace_bytes(B, c.n, t.d, n_groups, n_filter))
+        if phase == 1 and (getattr(self, "_ews", None) is None or self._ews.numel() < need):
+            self._ews = torch.empty(need, dtype=torch.uint8, device=self.device)       # lives across the three phases
+        sh = shard.c()
+        N.check(self.lib.okge_evaluate_fused_shard(int(phase), ctypes.byref(t), ctypes.byref(sh), Q.data_ptr(), Q.stride(0), int(B),
+                                                   ctypes.byref(c), int(n_cand_global), filt_ptr.data_ptr(),
+                                                   _ptr(filt_col) if n_filter else None, n_filter, row_ptr.data_ptr(),
+                                                   grp_ptr.data_ptr(), _ptr(ids), n_groups, true_scores.data_ptr(),
+                                                   counts.data_ptr(), self._ews.data_ptr(), self._ews.numel(), self._stream()),
+                "okge_evaluate_fused_shard")
+        del cid
+
     def rank_metrics(self, ranks, acc):
         """acc (7 device doubles) += {n, sum 1/(r+1), sum r, #r<1, #r<3, #r<10, #r<50}"""
         N.check(self.lib.okge_rank_metrics(ranks.data_ptr(), int(ranks.numel()), acc.data_ptr(), self._stream()),

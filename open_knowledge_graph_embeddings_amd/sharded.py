@@ -192,7 +192,17 @@ class ShardedTrainStep:
 
 class ShardedEvaluator:
     """Filtered ranks with the candidates sharded like the entity table (compute_metrics' rank rule,
-    dataset.py:423-446; exchange plan of SURVEY.md section 8e)."""
+    dataset.py:423-446; exchange plan of SURVEY.md section 8e).
+
+    `ranks()` runs the FUSED counting sweep on this rank's candidates (okge_evaluate_fused_shard; slot sizes up to 256):
+        exchange 1   the prefixes' entity rows -> folded queries (all-gather of the owned rows with an ExchangePlan, else
+                     all-reduce), as in training
+        points       every answer group's true score over the ids this rank holds       -> all-reduce(MAX)  [n_groups] floats
+        sweep        the local candidate tiles against the global true scores, counting > / == in registers
+        counts       + the filter correction for the filter columns this rank holds     -> all-reduce(SUM)  [n_groups, 2] int64
+        rank = #greater + #equal // 2: exact, identical on every rank, bit-equal to the single-device evaluation.
+    No (B, N / world) score block exists (5.1 GB per rank and batch at |E| = 2.5 M, B = 4096); `ranks_materialised()` keeps
+    the score-block path (any slot size)."""
 
     def __init__(self, E_local, R, scorer, n_ent, min_entities_size=2, engine=None, group=None):
         self.group = group
@@ -206,24 +216,62 @@ class ShardedEvaluator:
         c_lo = max(self.ent_lo, min_entities_size)
         self.cand_first_local = c_lo - self.ent_lo
         self.n_cand_local = max(0, self.ent_hi - c_lo)
+        self.n_cand_global = n_ent - min_entities_size
         self.col0 = c_lo - min_entities_size
         self.shard = H.Shard(self.ent_lo, self.ent_hi, self.col0)
 
-    def local_scores(self, batch: H.PrefixBatch):
+    def queries(self, batch: H.PrefixBatch, plan: ExchangePlan = None):
+        """folded query block of ALL prefixes on every rank (exchange 1 of the training step, eval mode)"""
         eng = self.engine
         er = eng.encode_entity_rows(self.E, self.R, self.scorer, batch, self.shard)
         if self.world > 1:
-            dist.all_reduce(er, group=self.group)
-        qe = (eng.fold_queries(self.E, self.R, self.scorer, batch, er), er)
-        local = H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
-                              cand_first=self.cand_first_local, n_cand=self.n_cand_local)
-        return eng.score_queries(self.E, self.R, self.scorer, qe[0], batch.B, local, self.shard)
+            if plan is None:
+                dist.all_reduce(er, group=self.group)
+            else:
+                mine = er.index_select(0, plan.owned[self.rank])             # [cap, ld]; padding rows are zero here
+                every = torch.empty((self.world * plan.cap, er.shape[1]), dtype=er.dtype, device=er.device)
+                dist.all_gather_into_tensor(every, mine, group=self.group)
+                er.zero_()
+                er[:batch.B] = every.index_select(0, plan.slot)
+        return eng.fold_queries(self.E, self.R, self.scorer, batch, er)
 
-    def ranks(self, batch: H.PrefixBatch, filt_ptr, filt_col, row_ptr, grp_ptr, ids):
+    def _local(self, batch):
+        return H.PrefixBatch(po_rel=batch.po_rel, po_obj=batch.po_obj, sp_subj=batch.sp_subj, sp_rel=batch.sp_rel,
+                             cand_first=self.cand_first_local, n_cand=self.n_cand_local)
+
+    def local_scores(self, batch: H.PrefixBatch, plan: ExchangePlan = None):
+        return self.engine.score_queries(self.E, self.R, self.scorer, self.queries(batch, plan), batch.B, self._local(batch),
+                                         self.shard)
+
+    def ranks(self, batch: H.PrefixBatch, filt_ptr, filt_col, row_ptr, grp_ptr, ids, plan: ExchangePlan = None):
         """int64 rank per answer group, identical on every rank.  Index arrays are global (positions in the full
         candidate list) and identical on every rank."""
+        if self.E.shape[1] > 256:
+            return self.ranks_materialised(batch, filt_ptr, filt_col, row_ptr, grp_ptr, ids, plan)
         eng = self.engine
-        x = self.local_scores(batch)
+        n_groups = int(grp_ptr.numel()) - 1
+        dev = self.E.device
+        counts = torch.zeros((max(n_groups, 1), 2), dtype=torch.int64, device=dev)
+        if n_groups == 0:
+            return counts[:0, 0]
+        Q = self.queries(batch, plan)
+        true = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+        local = self._local(batch)
+        args = (self.E, self.R, self.scorer, Q, batch.B, local, self.shard, self.n_cand_global, filt_ptr, filt_col, row_ptr,
+                grp_ptr, ids, true, counts)
+        if self.n_cand_local > 0:
+            eng.evaluate_fused_shard(1, *args)
+        dist.all_reduce(true, op=dist.ReduceOp.MAX, group=self.group)
+        if self.n_cand_local > 0:
+            eng.evaluate_fused_shard(2, *args)
+            eng.evaluate_fused_shard(4, *args)
+        dist.all_reduce(counts, group=self.group)
+        return counts[:n_groups, 0] + counts[:n_groups, 1] // 2
+
+    def ranks_materialised(self, batch: H.PrefixBatch, filt_ptr, filt_col, row_ptr, grp_ptr, ids, plan: ExchangePlan = None):
+        """the same ranks through this rank's (B, N / world) score block (any slot size)"""
+        eng = self.engine
+        x = self.local_scores(batch, plan)
         true = eng.group_true_scores(x, self.col0, row_ptr, grp_ptr, ids)
         dist.all_reduce(true, op=dist.ReduceOp.MAX, group=self.group)
         counts = eng.rank_counts(x, self.col0, filt_ptr, filt_col, row_ptr, true)

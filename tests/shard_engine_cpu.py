@@ -134,6 +134,16 @@ class OracleShardEngine:
                 out[g] = ((x[b] > tv[g]).sum(), (x[b] == tv[g]).sum())
         return torch.from_numpy(out)
 
+    def evaluate_fused_shard(self, phase, E_local, R, scorer, Q, B, batch, shard, n_cand_global, filt_ptr, filt_col, row_ptr,
+                             grp_ptr, ids, true_scores, counts):
+        """stand-in for okge_evaluate_fused_shard: same three phases and the same in-place buffers, through a local score
+        block (the group numbering of `true_scores` is the engine's own business: here the original one)"""
+        if phase == 1:
+            self._x = self.score_queries(E_local, R, scorer, Q, B, batch, shard)
+            true_scores.copy_(self.group_true_scores(self._x, shard.cand_col0, row_ptr, grp_ptr, ids))
+        elif phase == 4:
+            counts[:true_scores.numel()] = self.rank_counts(self._x, shard.cand_col0, filt_ptr, filt_col, row_ptr, true_scores)
+
     def train_tiles(self, E_local, R, scorer, Q, batch, shard, dE, dQ, n_cand_global, loss="bce", label_smoothing=0.0,
                     normalizer=None, loss_out=None, grads_zero=False, row_lse=None):
         d = E_local.shape[1]

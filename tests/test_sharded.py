@@ -114,12 +114,16 @@ def _worker(rank, world, port, outdir, nsteps, loss, use_plan=False):
                           engine=OracleShardEngine())
     eb = eval_problem()
     t = torch.from_numpy
+    from open_knowledge_graph_embeddings_amd.sharded import make_exchange_plan
+    eplan = make_exchange_plan(eb["po_obj"], eb["sp_subj"], N_ENT, world, "cpu") if use_plan else None
     ranks = ev.ranks(to_batch(eb, "cpu"), t(eb["filt_ptr"]), t(eb["filt_col"]), t(eb["row_ptr"]), t(eb["grp_ptr"]),
-                     t(eb["ids"]))
+                     t(eb["ids"]), plan=eplan)                       # fused protocol: points / MAX / sweep / counts / SUM
+    ranks_m = ev.ranks_materialised(to_batch(eb, "cpu"), t(eb["filt_ptr"]), t(eb["filt_col"]), t(eb["row_ptr"]),
+                                    t(eb["grp_ptr"]), t(eb["ids"]))
+    assert torch.equal(ranks, ranks_m)
     st = ShardedTrainStep(torch.from_numpy(E[lo:hi].copy()), torch.from_numpy(R.copy()), SCORER, N_ENT, lr=LR,
                           input_dropout=P_DROP, seed=SEED, engine=OracleShardEngine(), loss=loss)
     losses = []
-    from open_knowledge_graph_embeddings_amd.sharded import make_exchange_plan
     for step in range(1, nsteps + 1):
         pb = problem(step)
         plan = make_exchange_plan(pb["po_obj"], pb["sp_subj"], N_ENT, world, "cpu") if use_plan else None
@@ -516,6 +520,53 @@ def test_sharded_ranks_emulated_shards(world, okge_lib):
     np.testing.assert_array_equal(ranks, whole)
     ref = oracle_ranks(eb)
     assert (ranks != ref).mean() < 0.01 and np.abs(ranks - ref).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sharded_fused_ranks_emulated_shards(world, okge_lib):
+    """okge_evaluate_fused_shard over emulated shards -- points -> "all-reduce max" -> sweep -> counts -> "all-reduce sum" -- gives
+    the ranks of the single-device fused evaluation AND of score + filtered_ranks, bit for bit: no (B, N / world) score block"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.sharded import shard_range
+    hp = H.HotPath("cuda:0")
+    E, R = tables()
+    eb = eval_problem()
+    batch = to_batch(eb, "cuda:0")
+    Et, Rt = torch.from_numpy(E).cuda(), torch.from_numpy(R).cuda()
+    dev = lambda k: torch.from_numpy(eb[k]).cuda()      # noqa: E731
+    fp, fc, rp, gp, ids = dev("filt_ptr"), dev("filt_col"), dev("row_ptr"), dev("grp_ptr"), dev("ids")
+    whole = hp.filtered_ranks(hp.score(Et, Rt, SCORER, batch), fp, fc, rp, gp, ids).cpu().numpy()
+    fused, _ = hp.evaluate_fused(Et, Rt, SCORER, batch, fp, fc, rp, gp, ids)
+    np.testing.assert_array_equal(fused.cpu().numpy(), whole)
+    n_groups = int(gp.numel()) - 1
+    engines, shards, locals_, tables_ = [], [], [], []
+    for r in range(world):
+        lo, hi = shard_range(N_ENT, world, r)
+        c_lo = max(lo, 2)
+        shards.append(H.Shard(lo, hi, c_lo - 2))
+        tables_.append(Et[lo:hi].contiguous())
+        locals_.append(H.PrefixBatch(cand_first=c_lo - lo, n_cand=hi - c_lo))
+        engines.append(H.HotPath("cuda:0"))                       # one workspace per "rank": it lives across the phases
+    er = sum(hp.encode_entity_rows(tables_[r], Rt, SCORER, batch, shards[r]) for r in range(world))      # "exchange 1"
+    Q = hp.fold_queries(tables_[0], Rt, SCORER, batch, er)
+    trues = [torch.full((n_groups,), float("-inf"), device="cuda:0") for _ in range(world)]
+    counts = [torch.zeros((n_groups, 2), dtype=torch.int64, device="cuda:0") for _ in range(world)]
+    call = lambda ph, r, tr: engines[r].evaluate_fused_shard(ph, tables_[r], Rt, SCORER, Q, batch.B, locals_[r], shards[r],   # noqa: E731
+                                                             N_ENT - 2, fp, fc, rp, gp, ids, tr, counts[r])
+    for r in range(world):
+        call(1, r, trues[r])
+    true = torch.stack(trues).max(0).values                          # "all-reduce(MAX)"
+    assert bool(torch.isfinite(true).all())
+    for r in range(world):
+        g = true.clone()
+        call(2, r, g)
+        call(4, r, g)
+    total = sum(counts)                                              # "all-reduce(SUM)"
+    ranks = (total[:, 0] + total[:, 1] // 2).cpu().numpy()
+    np.testing.assert_array_equal(ranks, whole)
+    # every shard saw only its own columns: no shard alone has all the true scores (the maxima really were exchanged)
+    assert any(bool(torch.isinf(t_).any()) for t_ in trues) or world == 1
 
 
 @pytest.mark.gpu
