@@ -104,6 +104,47 @@ def cpu_baseline(w, host_batches, budget_s=20.0):
             "ms_per_step": 1e3 * el / steps}
 
 
+def run_dropin(w, host_batches, dev, steps=300, warmup=30):
+    """ms/step of the drop-in path (tools/bench_dropin.py has the slower configurations beside it): AddLossModule with
+    training_outputs=False, OkgeAdagrad, labels as column-sorted coordinates, the reference Trainer's statements verbatim"""
+    from open_knowledge_graph_embeddings_amd.dataset import EntityRelationDatasetMeta
+    from open_knowledge_graph_embeddings_amd.model import Models
+    from open_knowledge_graph_embeddings_amd.optim import OkgeAdagrad
+    from open_knowledge_graph_embeddings_amd.trainer import AddLossModule
+    torch.manual_seed(0)
+    m = Models.LookupComplexRelationModel(entity_slot_size=w.d, input_dropout=w.input_dropout, init_std=w.init_std, sparse=False,
+                                          train_data=EntityRelationDatasetMeta(entities_size=w.n_ent, relations_size=w.n_rel)).to(dev)
+    m.train()
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0, training_outputs=False)
+    opt = OkgeAdagrad(m.parameters(), lr=w.lr, weight_decay=1e-10, eps=1e-8)
+    cand = torch.arange(w.n_ent, device=dev)[2:].int().unsqueeze(1)
+    t = lambda a: torch.from_numpy(a).to(dev).unsqueeze(1)  # noqa: E731
+    batches = [([(t(hb["po_rel"]), t(hb["po_obj"])), (t(hb["sp_subj"]), t(hb["sp_rel"]))],
+                (torch.from_numpy(hb["pos_row"]).to(dev), torch.from_numpy(hb["pos_col"]).to(dev))) for hb in host_batches]
+    norm = float(w.B * w.N)
+
+    def step(i):
+        inputs, coords = batches[i % len(batches)]
+        opt.zero_grad()
+        loss, _, _ = mod(inputs=inputs, labels=coords, use_batch_shared_entities=False, batch_shared_entities=cand, epoch=1,
+                         input_style_triple_or_prefix="right_and_left_prefix")
+        (loss.sum() / norm).backward()
+        opt.step()
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    windows = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        windows.append(1e3 * (time.perf_counter() - t0) / steps)
+    return {"ms_per_step": float(np.median(windows)), "ms_per_step_min": min(windows), "ms_per_step_max": max(windows),
+            "steps": steps, "path": "Models.LookupComplexRelationModel + AddLossModule(training_outputs=False) + OkgeAdagrad, "
+                                    "coordinate labels, (loss.sum() / normalizer).backward() as trainer.py:217-234"}
+
+
 def run_olp(world, rank, dev, dist, barrier, steps=6, warmup=2):
     """S-OLP at the full size on `world` GPUs: tables generated on the device from per-row-block seeds (identical for
     every N), Zipf(1.1) prefix entity ids, one positive per row, dropout 0 (the reference's OLPBENCH
@@ -351,6 +392,13 @@ def main():
                 torch.cuda.synchronize()
                 ev["pipelined_steady_ms_per_batch"] = 1e3 * (time.perf_counter() - t0) / 640
 
+    # ---- drop-in leg (single GPU, untimed region like `eval`): the reference Trainer's own step sequence (trainer.py:206-244:
+    #      zero_grad, AddLossModule forward, (loss.sum() / normalizer).backward(), optimizer.step()) on this package's Models /
+    #      AddLossModule / OkgeAdagrad -- what a user of INTEGRATION.md section 1 gets without touching the training loop
+    dropin = None
+    if rank == 0 and not sharded and args.workload == "S-FB" and os.environ.get("OKGE_BENCH_DROPIN", "1") == "1":
+        dropin = run_dropin(w, host_batches, dev)
+
     # ---- the north-star's second shape: S-OLP (|E| = 2.5 M, |R| = 100 k, d = 256, B = 4096, Zipf(1.1) prefix entities),
     #      the SAME global problem at every N (strong scaling), entity table row-sharded over the ranks; a handful of steps
     olp = None
@@ -379,7 +427,7 @@ def main():
                    "global_batch": w_run.B,
                    "parallelism": f"entity table row-sharded x{world}, batch 512 x{world}" if sharded else "single"},
         "prefixes_per_s": w_run.B * args.steps / elapsed, "last_loss_sum": loss_last,
-        "roofline": roof, "cpu_baseline": cpu, "eval": ev, "olp": olp,
+        "roofline": roof, "cpu_baseline": cpu, "eval": ev, "dropin": dropin, "olp": olp,
     }
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())

@@ -253,6 +253,12 @@ int okge_score_triples(int32_t scorer, const float *subj, int64_t ld_subj, const
 /* x[i] *= *alpha_dev for i < n (alpha is a DEVICE fp32 scalar: the upstream gradient autograd hands to the
  * fused loss node, i.e. 1/normalizer of trainer.py:221, without a host synchronisation). */
 int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream);
+/* The same hand-over when the caller already folded a factor into the gradients: the reference Trainer always divides the
+ * summed loss by normalizer_loss = B x N (dataset.py:935, trainer.py:221), so AddLossModule runs the fused step with that
+ * normalizer and the gradients need NO pass at all when autograd's upstream scalar turns out to be the same fp32 number:
+ * g0, g1 *= *alpha_dev / applied, in one launch that reads nothing but the scalar when the ratio is exactly 1
+ * (otherwise it rescales: correct for any upstream gradient, only slower). */
+int okge_rescale_gradients(float *g0, int64_t n0, float *g1, int64_t n1, const float *alpha_dev, float applied, void *stream);
 
 /* ---- dense Adagrad ----------------------------------------------------------------------------------
  * Replaces torch.optim.Adagrad.step as configured by OptimRegime (utils/optim.py:29,139-160):

@@ -32,7 +32,7 @@ EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_t
            "okge_prefix_backward", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
            "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_shard", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
            "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
-           "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
+           "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_rescale_gradients", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
 
 
@@ -244,6 +244,8 @@ def lib():
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     L.okge_scale_inplace.restype = c_int32
     L.okge_scale_inplace.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
+    L.okge_rescale_gradients.restype = c_int32
+    L.okge_rescale_gradients.argtypes = [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_float, c_void_p]
     L.okge_adagrad_step.restype = c_int32
     L.okge_adagrad_step.argtypes = [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int32, c_void_p]
     L.okge_adagrad_step2.restype = c_int32

@@ -821,6 +821,17 @@ int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream
     return OKGE_OK;
 }
 
+int okge_rescale_gradients(float *g0, int64_t n0, float *g1, int64_t n1, const float *alpha_dev, float applied, void *stream)
+{
+    if (!g0 || !alpha_dev || n0 < 0 || n1 < 0 || (n1 > 0 && !g1) || !(applied > 0.f))
+        return fail(OKGE_ERR_INVALID, "bad rescale arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("rescale", st);
+    hipError_t e = launch_rescale2(g0, n0, g1 ? g1 : g0, g1 ? n1 : 0, alpha_dev, applied, st);
+    if (e != hipSuccess) return fail_hip(e, "rescale");
+    return OKGE_OK;
+}
+
 int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr, float weight_decay, float eps,
                       int32_t zero_grad, void *stream)
 {

@@ -115,6 +115,7 @@ hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, flo
 hipError_t launch_encode_rows(const float *table, int64_t table_rows, int d, const int32_t *ids, int first_id, int n,
                               const DropDev &drop, float *out, int64_t ld_out, int *id_err, hipStream_t st);
 hipError_t launch_scale(float *x, int64_t n, const float *alpha_dev, hipStream_t st);
+hipError_t launch_rescale2(float *x0, int64_t n0, float *x1, int64_t n1, const float *alpha_dev, float applied, hipStream_t st);
 hipError_t launch_adagrad(float *p, float *g, float *sum, int64_t n, float lr, float wd, float eps, int zero_grad,
                           hipStream_t st);
 hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p1, float *g1, float *s1, int64_t n1,

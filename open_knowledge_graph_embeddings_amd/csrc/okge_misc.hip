@@ -513,6 +513,19 @@ __global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ x, int64
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= a;
 }
 
+// The drop-in path's gradients come out of the fused step already multiplied by `applied` = the 1 / normalizer the reference
+// Trainer is known to divide by (trainer.py:221); autograd later hands over the factor it really used (*alpha).  Both
+// tensors in one launch, and nothing but the scalar is read when the two agree (the normal case): x *= alpha / applied.
+__global__ __launch_bounds__(256) void rescale2_kernel(float *__restrict__ x0, int64_t n0, float *__restrict__ x1, int64_t n1,
+                                                       const float *__restrict__ alpha, float applied)
+{
+    const float r = *alpha / applied;
+    if (r == 1.0f) return;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0; i += stride) x0[i] *= r;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += stride) x1[i] *= r;
+}
+
 struct AdagradSeg { float *p, *g, *s; int64_t n; };
 
 __device__ __forceinline__ void adagrad_sweep(const AdagradSeg sg, float lr, float wd, float eps, int zero_grad,
@@ -980,6 +993,15 @@ hipError_t launch_scale(float *x, int64_t n, const float *alpha_dev, hipStream_t
     if (n <= 0) return hipSuccess;
     const int blocks = (int)std::min((int64_t)4096, (n + 255) / 256);
     hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, st, x, n, alpha_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_rescale2(float *x0, int64_t n0, float *x1, int64_t n1, const float *alpha_dev, float applied, hipStream_t st)
+{
+    const int64_t n = std::max(n0, n1);
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int)std::min((int64_t)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(rescale2_kernel, dim3(blocks), dim3(256), 0, st, x0, n0, x1, n1, alpha_dev, applied);
     return hipGetLastError();
 }
 

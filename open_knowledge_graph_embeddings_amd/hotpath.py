@@ -394,6 +394,11 @@ class HotPath:
                 "okge_scale_inplace")
         return x
 
+    def rescale_gradients_(self, g0, g1, alpha_dev, applied):
+        """g0, g1 *= alpha / applied (alpha: device fp32 scalar) in ONE launch; free when the two are the same number"""
+        N.check(self.lib.okge_rescale_gradients(g0.data_ptr(), g0.numel(), g1.data_ptr(), g1.numel(), alpha_dev.data_ptr(),
+                                                float(applied), self._stream()), "okge_rescale_gradients")
+
     def adagrad(self, p, g, state_sum, lr, weight_decay=1e-10, eps=1e-8, zero_grad=True):
         N.check(self.lib.okge_adagrad_step(p.data_ptr(), g.data_ptr(), state_sum.data_ptr(), p.numel(), float(lr),
                                            float(weight_decay), float(eps), 1 if zero_grad else 0, self._stream()),

@@ -8,6 +8,7 @@ the returned loss is wired into autograd by a custom Function so the reference T
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch.nn import BCEWithLogitsLoss, KLDivLoss
@@ -17,21 +18,22 @@ from .metrics import MetricResult
 
 
 class _FusedLossFn(torch.autograd.Function):
-    """Autograd node standing for AddLossModule's whole forward: the gradients of the SUMMED loss were already
-    produced by the fused kernel; backward scales them by the upstream scalar (1/normalizer) on the device."""
+    """Autograd node standing for AddLossModule's whole forward: the gradients were already produced by the fused kernel,
+    multiplied by `applied` = the 1 / (B N) the reference Trainer divides the summed loss by (dataset.py:935, trainer.py:221).
+    backward compares that with the upstream scalar autograd delivers -- on the device, no host read -- and rescales only
+    if they differ (one launch that reads a single float when they agree; before: two passes over 11.6 MB)."""
 
     @staticmethod
-    def forward(ctx, e_weight, r_weight, loss, g_e, g_r, engine):
-        ctx.g_e, ctx.g_r, ctx.engine = g_e, g_r, engine
+    def forward(ctx, e_weight, r_weight, loss, g_e, g_r, engine, applied):
+        ctx.g_e, ctx.g_r, ctx.engine, ctx.applied = g_e, g_r, engine, applied
         return loss.to(torch.float32).reshape(())               # (the cast already yields a fresh tensor)
 
     @staticmethod
     def backward(ctx, grad_out):
         alpha = grad_out.reshape(1).to(torch.float32).contiguous()
         g_e, g_r, ctx.g_e, ctx.g_r = ctx.g_e, ctx.g_r, None, None   # no reference left behind: AccumulateGrad then TAKES the
-        ctx.engine.scale_(g_e, alpha)                               # buffers as .grad instead of copying them (an 11.6 MB
-        ctx.engine.scale_(g_r, alpha)                               # copy per step at FB15k-237)
-        return g_e, g_r, None, None, None, None
+        ctx.engine.rescale_gradients_(g_e, g_r, alpha, ctx.applied) # buffers as .grad instead of copying them (an 11.6 MB
+        return g_e, g_r, None, None, None, None, None               # copy per step at FB15k-237)
 
 
 def _flat(t):
@@ -167,9 +169,16 @@ class AddLossModule(nn.Module):
             else:
                 g_e = torch.zeros_like(m.E)
             g_r = torch.zeros_like(m.R)
+            # the factor the Trainer will apply (trainer.py:221: loss / normalizer_loss, normalizer_loss = B x N,
+            # dataset.py:935) goes into the fused step; _FusedLossFn.backward checks it against what autograd delivers
+            # (torch divides a fp32 tensor by a Python number as a multiplication by fp32(1) / fp32(number), forward and
+            #  backward: `applied` is built the same way, and the normalizer handed to the library is the one whose fp32
+            #  reciprocal is exactly that)
+            applied = np.float32(1.0) / np.float32(float(B) * float(n))
             loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, g_e, g_r, loss=kind, label_smoothing=smoothing,
-                                        normalizer=1.0, scores=all_outputs, grads_zero=True)
-            result = _FusedLossFn.apply(m.entity_embedding.weight, m.relation_embedding.weight, loss, g_e, g_r, eng)
+                                        normalizer=1.0 / float(applied), scores=all_outputs, grads_zero=True)
+            result = _FusedLossFn.apply(m.entity_embedding.weight, m.relation_embedding.weight, loss, g_e, g_r, eng,
+                                        float(applied))
         else:
             loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, None, None, loss=kind, label_smoothing=smoothing,
                                         normalizer=1.0, scores=all_outputs, loss_only=True)

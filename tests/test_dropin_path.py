@@ -108,6 +108,34 @@ def test_addloss_without_training_outputs_and_okge_adagrad_step(okge_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("factor", [1.0, 2.5, "other_normalizer", "sum_of_two"])
+def test_addloss_gradient_scale_follows_the_upstream_gradient(okge_lib, factor):
+    """AddLossModule folds the Trainer's 1 / (B N) into the fused step and _FusedLossFn.backward rescales on the device only
+    if autograd's upstream scalar is another number: the reference's own expression (factor 1.0: nothing to rescale), a
+    multiple of it, a different normalizer, and a loss used twice in the graph all give the right gradient"""
+    from open_knowledge_graph_embeddings_amd.trainer import AddLossModule
+    z = golden("g2_loss_complex_bce_all")
+    m = _lookup_model(z)
+    m.train()
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0, training_outputs=False)
+    inputs = [(_dev(z["po_rel"]), _dev(z["po_obj"])), (_dev(z["sp_subj"]), _dev(z["sp_rel"]))]
+    loss, _, _ = mod(inputs=inputs, labels=_dev(z["labels"]), use_batch_shared_entities=False,
+                     batch_shared_entities=_dev(z["cand"]), epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+    norm = float(z["normalizer"])
+    if factor == "other_normalizer":
+        (loss.sum() / 123.0).backward()
+        scale = norm / 123.0
+    elif factor == "sum_of_two":
+        (loss.sum() / norm + 0.5 * loss / norm).backward()
+        scale = 1.5
+    else:
+        (factor * loss.sum() / norm).backward()
+        scale = factor
+    for g, ref in ((m.entity_embedding.weight.grad, z["dE"]), (m.relation_embedding.weight.grad, z["dR"])):
+        np.testing.assert_allclose(g.cpu().numpy(), scale * ref, rtol=0, atol=3e-5 * scale * np.abs(ref).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", golden_names("g9_unigram_"))
 def test_addloss_on_token_pooled_models(okge_lib, name):
     """AddLossModule + autograd on UnigramPoolingComplexRelationModel: the reference Trainer's own path, vs the
