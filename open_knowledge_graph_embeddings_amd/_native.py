@@ -29,7 +29,7 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 # every symbol include/okge.h declares
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_score_workspace_bytes", "okge_lse_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
-           "okge_prefix_backward", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
+           "okge_prefix_backward", "okge_prefix_backward_segmented", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
            "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_shard", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward",
            "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
            "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_rescale_gradients", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
@@ -201,6 +201,10 @@ def lib():
     L.okge_prefix_backward.restype = c_int32
     L.okge_prefix_backward.argtypes = [POINTER(Tables), POINTER(Shard), POINTER(PrefixBatch), c_void_p, c_int64, c_void_p,
                                        c_void_p, c_void_p, c_void_p]
+    L.okge_prefix_backward_segmented.restype = c_int32
+    L.okge_prefix_backward_segmented.argtypes = [POINTER(Tables), POINTER(Shard), POINTER(PrefixBatch), c_void_p, c_int64, c_void_p,
+                                                 c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p]
     L.okge_encode_rows.restype = c_int32
     L.okge_encode_rows.argtypes = [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, POINTER(Dropout), c_void_p,
                                    c_int64, c_void_p]

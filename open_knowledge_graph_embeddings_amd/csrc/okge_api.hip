@@ -707,6 +707,34 @@ int okge_prefix_backward(const okge_tables *t, const okge_shard *sh, const okge_
     return OKGE_OK;
 }
 
+int okge_prefix_backward_segmented(const okge_tables *t, const okge_shard *sh, const okge_prefix_batch *batch, const float *dQ,
+                                   int64_t ldq, const float *ent_rows, const int32_t *rel_order, const int32_t *rel_seg_ptr,
+                                   int32_t n_rel_seg, const int32_t *ent_order, const int32_t *ent_seg_ptr, int32_t n_ent_seg,
+                                   float *grad_rows, float *dE, float *dR, void *stream)
+{
+    okge_candidates none;
+    std::memset(&none, 0, sizeof(none));
+    none.n = 1; none.first_id = 0;
+    if (int rc = check_common(t, batch, &none)) return rc;
+    if (int rc = check_shard(t, sh)) return rc;
+    if (!dQ || !dE || !dR || ldq != okge_query_ld(t->d)) return fail(OKGE_ERR_INVALID, "bad prefix_backward arguments");
+    const int B = batch->n_po + batch->n_sp;
+    const bool has_r = rel_order || rel_seg_ptr || n_rel_seg, has_e = ent_order || ent_seg_ptr || n_ent_seg;
+    if (!grad_rows || (!has_r && !has_e) || (has_r && (!rel_order || !rel_seg_ptr || n_rel_seg <= 0 || n_rel_seg > B)) ||
+        (has_e && (!ent_order || !ent_seg_ptr || n_ent_seg <= 0 || n_ent_seg > B)))
+        return fail(OKGE_ERR_INVALID, "bad row segments (order[B], seg_ptr[n_seg + 1], 1 <= n_seg <= B; grad_rows[2][rows][ldq])");
+    const bool vec = t->scorer == OKGE_DISTMULT ? (t->d % 4 == 0) : (t->d % 8 == 0);
+    if (!vec) return fail(OKGE_ERR_UNSUPPORTED, "segmented gradients need d % 8 == 0 (ComplEx) / d % 4 == 0 (DistMult)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const PrefixDev p = to_dev(*batch, t, sh);
+    ScopedTimer tm("prefix_backward", st);
+    hipError_t e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, dQ, 1, okge_query_rows(B), (int)ldq, ent_rows,
+                                          dE, dR, nullptr, 0, nullptr, st, rel_order, rel_seg_ptr, n_rel_seg, ent_order,
+                                          ent_seg_ptr, n_ent_seg, grad_rows);
+    if (e != hipSuccess) return fail_hip(e, "prefix_backward_segmented");
+    return OKGE_OK;
+}
+
 int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const int32_t *ids, int32_t first_id, int32_t n,
                      const okge_dropout *drop, float *out, int64_t ld_out, void *stream)
 {

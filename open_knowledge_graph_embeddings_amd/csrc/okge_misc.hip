@@ -315,14 +315,22 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v)
 // lanes of a column group sum disjoint quarters of the nsplit dQ slabs (all their loads are issued at once) and
 // combine with two shuffles; sq == 0 then applies the chain rule and scatters.  Needs d % 8 == 0 (ComplEx) or
 // d % 4 == 0 (DistMult).  The last workgroup (blockIdx.x == gridDim.x - 1) instead sums the loss partials.
+// NB: slab loads kept in flight per lane (8 for the single-device step's 32 split-K slabs; 1 for the sharded step, whose dQ
+// arrives already reduced: 89 instead of 149 registers = 5 instead of 3 waves per SIMD, which is what bounds a launch of
+// 4096 one-row workgroups -- 2.7 rounds of a ~7 us dependent-load chain at 3 waves)
+template <int NB>
 __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                                   int d, int scorer, const PrefixDev p,
                                                                   const float *__restrict__ slab, int nsplit, int Bpad,
                                                                   int ldq, const float *__restrict__ ent_rows,
                                                                   float *__restrict__ dE, float *__restrict__ dR,
                                                                   const double *__restrict__ loss_partials,
-                                                                  int n_partials, double *__restrict__ loss_out)
+                                                                  int n_partials, double *__restrict__ loss_out,
+                                                                  float *__restrict__ dr_rows, float *__restrict__ de_rows)
 {
+    // dr_rows / de_rows ([B][ldq] each, or nullptr): the relation- / entity-gradient row of every batch row is STORED there
+    // instead of being added into dR / dE with float atomics -- row_segment_sum_kernel then adds up the rows of each
+    // relation / entity (okge_prefix_backward_segmented)
     if (blockIdx.x == gridDim.x - 1) {
         if (loss_partials) loss_reduce_block(loss_partials, n_partials, loss_out);
         return;
@@ -334,21 +342,31 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
     const DropDev &dr = rs.sp ? p.drop_sp_rel : p.drop_po_rel;
     const float *e = ent_rows ? ent_rows + (size_t)b * ldq : E + rs.ent * d, *r = R + rs.rel * d;
     const bool e_masked = ent_rows != nullptr;
-    float *ge = dE + (rs.owned ? rs.ent : 0) * d, *gr = dR + rs.rel * d;
+    float *ge = de_rows ? de_rows + (size_t)b * ldq : dE + (rs.owned ? rs.ent : 0) * d;
+    float *gr = dr_rows ? dr_rows + (size_t)b * ldq : dR + rs.rel * d;
     const size_t split_stride = (size_t)Bpad * ldq;
     const float *sl = slab + (size_t)b * ldq;
     const int s_lo = (nsplit * sq) >> 2, s_hi = (nsplit * (sq + 1)) >> 2;
+    auto put_r = [&](float *pr, float4 v) {      // relation gradient: a row of its own (plain store) or an atomic add into dR
+        if (dr_rows) *reinterpret_cast<float4 *>(pr) = v;
+        else atomic_add4(pr, v);
+    };
+    auto put_e = [&](float *pe, float4 v) {
+        if (de_rows) *reinterpret_cast<float4 *>(pe) = v;
+        else atomic_add4(pe, v);
+    };
     auto dq_sum = [&](int k, bool active) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
             int sidx = s_lo;
-            for (; sidx + 8 <= s_hi; sidx += 8) {
-                float4 v[8];
+            if (NB > 1)
+                for (; sidx + NB <= s_hi; sidx += NB) {
+                    float4 v[NB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(sl + (sidx + u) * split_stride + k);
+                    for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const float4 *>(sl + (sidx + u) * split_stride + k);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-            }
+                    for (int u = 0; u < NB; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
             for (; sidx < s_hi; ++sidx) {
                 const float4 v = *reinterpret_cast<const float4 *>(sl + sidx * split_stride + k);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -387,8 +405,8 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
                 const float4 me = mult4(de, nib_e), mr = mult4(dr, nib_r);
                 const float4 ev = e_masked ? ev0 : f4mul(ev0, me);
                 const float4 rv = f4mul(rv0, mr);
-                if (rs.owned) atomic_add4(ge + k, f4mul(f4mul(dq, rv), me));
-                atomic_add4(gr + k, f4mul(f4mul(dq, ev), mr));
+                if (rs.owned) put_e(ge + k, f4mul(f4mul(dq, rv), me));
+                put_r(gr + k, f4mul(f4mul(dq, ev), mr));
             }
         }
         return;
@@ -420,11 +438,50 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
             dr1 = f4fma(q1, e1, f4mul(q2, e2));           dr2 = f4fma(q1, e2, f4neg(f4mul(q2, e1)));
         }
         if (rs.owned) {
-            atomic_add4(ge + k, f4mul(de1, me1));
-            atomic_add4(ge + h + k, f4mul(de2, me2));
+            put_e(ge + k, f4mul(de1, me1));
+            put_e(ge + h + k, f4mul(de2, me2));
         }
-        atomic_add4(gr + k, f4mul(dr1, mr1));
-        atomic_add4(gr + h + k, f4mul(dr2, mr2));
+        put_r(gr + k, f4mul(dr1, mr1));
+        put_r(gr + h + k, f4mul(dr2, mr2));
+    }
+}
+
+// dR[relation] / dE[entity] += the gradient rows of the batch rows that name this relation / entity, in the plan's (stable)
+// order: one workgroup per segment, one float4 column group per thread -- plain loads and ONE read-modify-write per table
+// row, no float atomics (1.6 M of them at the 8-rank FB15k-237 shape: 4096 batch rows x 200 columns x 2 tables, 17 batch
+// rows per relation) and a fixed summation order.  order[] = batch rows sorted by id, seg_ptr[] = the bounds of the runs of
+// equal ids (host-built, like the exchange plan: the ids are on the host before the batch is uploaded).  Workgroups
+// 0 .. n_rel_seg-1 take the relation segments, the rest the entity segments (skipped when another rank owns the entity).
+struct RowSegments { const int32_t *order, *seg_ptr; int32_t n_seg; };
+__global__ __launch_bounds__(128) void row_segment_sum_kernel(const float *__restrict__ dr_rows, const float *__restrict__ de_rows,
+                                                              int ldq, int d, const PrefixDev p, const RowSegments rel,
+                                                              const RowSegments ent, float *__restrict__ dR, float *__restrict__ dE)
+{
+    const bool is_rel = (int)blockIdx.x < rel.n_seg;
+    const RowSegments &sg = is_rel ? rel : ent;
+    const int sidx = is_rel ? blockIdx.x : blockIdx.x - rel.n_seg;
+    const int lo = sg.seg_ptr[sidx], hi = sg.seg_ptr[sidx + 1];
+    if (hi <= lo) return;
+    const int B = p.n_po + p.n_sp;
+    const RowSrc rs = row_source(p, min(max(sg.order[lo], 0), B - 1), false);
+    if (!is_rel && !rs.owned) return;
+    const float *rows = is_rel ? dr_rows : de_rows;
+    float *dst = is_rel ? dR + rs.rel * d : dE + rs.ent * d;
+    for (int k = 4 * threadIdx.x; k < d; k += 4 * 128) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lo; i < hi; ++i) {
+            const int b = min(max(sg.order[i], 0), B - 1);
+            const float4 v = *reinterpret_cast<const float4 *>(rows + (size_t)b * ldq + k);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if (k + 4 <= d) {
+            float4 o = *reinterpret_cast<const float4 *>(dst + k);
+            o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+            *reinterpret_cast<float4 *>(dst + k) = o;
+        } else {
+            const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+            for (int e = 0; k + e < d; ++e) dst[k + e] += v[e];
+        }
     }
 }
 
@@ -930,14 +987,28 @@ hipError_t launch_dc_reduce_streamk(const float *slab, int tiles, int chunks_per
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
                                   const float *slab, int nsplit, int Bpad, int ldq, const float *ent_rows, float *dE,
                                   float *dR, const double *loss_partials, int n_partials, double *loss_out,
-                                  hipStream_t st)
+                                  hipStream_t st, const int32_t *rel_order, const int32_t *rel_seg_ptr, int n_rel_seg,
+                                  const int32_t *ent_order, const int32_t *ent_seg_ptr, int n_ent_seg, float *grad_rows)
 {
     const int B = p.n_po + p.n_sp;
     if (B <= 0) return hipSuccess;
     const bool vec = scorer == SC_DISTMULT ? (d % 4 == 0) : (d % 8 == 0);
     if (vec) {
-        hipLaunchKernelGGL(prefix_backward_vec_kernel, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
-                           nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out);
+        // grad_rows: [2][Bpad][ldq] scratch -- relation rows, then entity rows
+        const bool seg_r = grad_rows && rel_order && rel_seg_ptr && n_rel_seg > 0;
+        const bool seg_e = grad_rows && ent_order && ent_seg_ptr && n_ent_seg > 0;
+        float *dr_rows = seg_r ? grad_rows : nullptr, *de_rows = seg_e ? grad_rows + (size_t)Bpad * ldq : nullptr;
+        if (nsplit >= 8)
+            hipLaunchKernelGGL(prefix_backward_vec_kernel<8>, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
+                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows);
+        else
+            hipLaunchKernelGGL(prefix_backward_vec_kernel<1>, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
+                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows);
+        if (seg_r || seg_e) {
+            const RowSegments rel{rel_order, rel_seg_ptr, seg_r ? n_rel_seg : 0}, ent{ent_order, ent_seg_ptr, seg_e ? n_ent_seg : 0};
+            hipLaunchKernelGGL(row_segment_sum_kernel, dim3(rel.n_seg + ent.n_seg), dim3(128), 0, st, dr_rows, de_rows, ldq, d, p,
+                               rel, ent, dR, dE);
+        }
     } else {
         hipLaunchKernelGGL(prefix_backward_kernel, dim3(B), dim3(128), 0, st, E, R, d, scorer, p, slab, nsplit, Bpad, ldq,
                            ent_rows, dE, dR);

@@ -352,10 +352,26 @@ class HotPath:
         del keep
         return out
 
-    def prefix_backward(self, E_local, R, scorer, batch: PrefixBatch, shard: Shard, dQ, ent_rows, dE, dR):
+    def prefix_backward(self, E_local, R, scorer, batch: PrefixBatch, shard: Shard, dQ, ent_rows, dE, dR, rel_segments=None):
+        """rel_segments: sharded.RowSegments (make_row_segments) -- relation and / or entity gradients by sorted segments
+        instead of float atomics"""
         pb, c, keep = self._batch(batch)
         t = self._tables(E_local, R, scorer)
         sh = shard.c()
+        if rel_segments is not None:
+            sg = rel_segments
+            if getattr(self, "_grad_rows", None) is None or self._grad_rows.shape[1:] != dQ.shape:
+                self._grad_rows = torch.empty((2,) + tuple(dQ.shape), dtype=dQ.dtype, device=dQ.device)
+            r_o, r_p = sg.rel if sg.rel is not None else (None, None)
+            e_o, e_p = sg.ent if sg.ent is not None else (None, None)
+            N.check(self.lib.okge_prefix_backward_segmented(ctypes.byref(t), ctypes.byref(sh), ctypes.byref(pb), dQ.data_ptr(),
+                                                            dQ.stride(0), _ptr(ent_rows), _ptr(r_o), _ptr(r_p),
+                                                            0 if r_p is None else int(r_p.numel()) - 1, _ptr(e_o), _ptr(e_p),
+                                                            0 if e_p is None else int(e_p.numel()) - 1, self._grad_rows.data_ptr(),
+                                                            dE.data_ptr(), dR.data_ptr(), self._stream()),
+                    "okge_prefix_backward_segmented")
+            del keep
+            return
         N.check(self.lib.okge_prefix_backward(ctypes.byref(t), ctypes.byref(sh), ctypes.byref(pb), dQ.data_ptr(),
                                               dQ.stride(0), _ptr(ent_rows), dE.data_ptr(), dR.data_ptr(),
                                               self._stream()), "okge_prefix_backward")

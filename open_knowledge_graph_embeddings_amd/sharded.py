@@ -77,6 +77,39 @@ def make_exchange_plan(po_obj, sp_subj, n_ent, world, device):
     return ExchangePlan(cap, owned, torch.from_numpy(slot).to(device))
 
 
+class RowSegments:
+    """Host-built plans for the prefix backward (okge_prefix_backward_segmented): batch rows grouped by relation id (`rel`)
+    and by prefix entity id (`ent`), each (order int32[B], seg_ptr int32[n_seg + 1]) on the device, or None = keep atomics."""
+
+    def __init__(self, rel=None, ent=None):
+        self.rel, self.ent = rel, ent
+
+
+def _segments(ids, device):
+    import numpy as np
+    order = np.argsort(ids, kind="stable")
+    srt = ids[order]
+    heads = np.flatnonzero(np.concatenate([[True], srt[1:] != srt[:-1]]))
+    seg_ptr = np.concatenate([heads, [ids.size]])
+    return (torch.from_numpy(order.astype(np.int32)).to(device), torch.from_numpy(seg_ptr.astype(np.int32)).to(device)), len(heads)
+
+
+def make_row_segments(po_rel, po_obj, sp_subj, sp_rel, device, min_rows=1024, min_rows_per_relation=4.0):
+    """HOST int arrays of the global batch (po rows first) -> RowSegments, or None for batches where the float atomics are
+    cheaper than a second launch: fewer than `min_rows` rows (0.2 M atomics = 4 us at B = 512; the segment launch costs
+    about that).  The relation plan is left out when relations hardly repeat (fewer than `min_rows_per_relation` rows per
+    distinct relation: |R| = 100 k at the OLPBENCH shape), the entity plan is kept (one segment per distinct entity: plain
+    read-modify-write instead of B x d atomics)."""
+    import numpy as np
+    rel = np.concatenate([np.asarray(po_rel, np.int64).reshape(-1), np.asarray(sp_rel, np.int64).reshape(-1)])
+    ent = np.concatenate([np.asarray(po_obj, np.int64).reshape(-1), np.asarray(sp_subj, np.int64).reshape(-1)])
+    if rel.size == 0 or rel.size < min_rows or rel.size != ent.size:
+        return None
+    r, n_r = _segments(rel, device)
+    e, _ = _segments(ent, device)
+    return RowSegments(rel=r if rel.size >= min_rows_per_relation * n_r else None, ent=e)
+
+
 class ShardedTrainStep:
     def __init__(self, E_local, R, scorer, n_ent, min_entities_size=2, lr=0.3, weight_decay=1e-10, eps=1e-8,
                  loss="bce", label_smoothing=0.0, input_dropout=0.0, relation_input_dropout=0.0, seed=0, engine=None,
@@ -134,9 +167,10 @@ class ShardedTrainStep:
         er[:batch.B] = every.index_select(0, plan.slot)
         return er
 
-    def step(self, batch: H.PrefixBatch, plan: ExchangePlan = None):
+    def step(self, batch: H.PrefixBatch, plan: ExchangePlan = None, rel_segments=None):
         """`batch` is the GLOBAL batch (identical on every rank); 1-vs-all candidates; positives carry global columns.
-        `plan` (make_exchange_plan, optional): exchange 1 as an all-gather of owned rows instead of an all-reduce."""
+        `plan` (make_exchange_plan, optional): exchange 1 as an all-gather of owned rows instead of an all-reduce.
+        `rel_segments` (make_row_segments, optional): relation / entity gradients by sorted segments instead of float atomics."""
         if batch.cand_ids is not None:
             raise NotImplementedError("batch-shared sampled candidates are too few to shard: use replicas")
         self.steps += 1
@@ -175,7 +209,10 @@ class ShardedTrainStep:
         if self.world > 1 or self.force_exchange:
             dist.all_reduce(dq, group=self.group)
         # 3. chain rule: entity rows by their owner, relation rows everywhere (identical)
-        eng.prefix_backward(self.E, self.R, self.scorer, batch, self.shard, dq, qe[1], self.dE, self.dR)
+        if rel_segments is not None:
+            eng.prefix_backward(self.E, self.R, self.scorer, batch, self.shard, dq, qe[1], self.dE, self.dR, rel_segments=rel_segments)
+        else:
+            eng.prefix_backward(self.E, self.R, self.scorer, batch, self.shard, dq, qe[1], self.dE, self.dR)
         # 4. dense Adagrad on the local entity rows and on the replicated relation table
         eng.adagrad2(self.E, self.dE, self.sumE, self.R, self.dR, self.sumR, self.lr, self.weight_decay, self.eps,
                      zero_grad=True)

@@ -196,7 +196,8 @@ class OracleShardEngine:
         loss_out[0] = out["loss"]
         return loss_out
 
-    def prefix_backward(self, E_local, R, scorer, batch, shard, dQ, ent_rows, dE, dR):
+    def prefix_backward(self, E_local, R, scorer, batch, shard, dQ, ent_rows, dE, dR, rel_segments=None):
+        # (rel_segments: how the relation rows are ADDED UP on the device; the sum itself is the same)
         kind = ko.KIND_NAMES[scorer]
         d = E_local.shape[1]
         er = _np(ent_rows)

@@ -128,7 +128,10 @@ def _worker(rank, world, port, outdir, nsteps, loss, use_plan=False):
         pb = problem(step)
         plan = make_exchange_plan(pb["po_obj"], pb["sp_subj"], N_ENT, world, "cpu") if use_plan else None
         assert not use_plan or plan is not None
-        st.step(to_batch(pb, "cpu"), plan=plan)
+        from open_knowledge_graph_embeddings_amd.sharded import make_row_segments
+        segs = make_row_segments(pb["po_rel"], pb["po_obj"], pb["sp_subj"], pb["sp_rel"], "cpu", min_rows=1,
+                                 min_rows_per_relation=1.0) if use_plan else None
+        st.step(to_batch(pb, "cpu"), plan=plan, rel_segments=segs)
         losses.append(float(st.reduce_loss()[0]))
     # checkpoint interop: shards gathered into the reference's state-dict layout, then scattered back
     from open_knowledge_graph_embeddings_amd.checkpoint import load_reference_checkpoint, save_checkpoint
@@ -386,6 +389,76 @@ def test_replica_step_protocol_gloo():
     np.testing.assert_allclose(parts[0]["stat"], [(0 + 1 + 1 + 1) / 2.0] * 2)        # mean of (rank + 1) over the ranks
     np.testing.assert_array_equal(parts[0]["stat"], parts[1]["stat"])
     np.testing.assert_allclose(parts[0]["loss"], [(x.sum() * 1 + x.sum() * 2) / norm])
+
+
+def test_row_segments_plan():
+    from open_knowledge_graph_embeddings_amd.sharded import make_row_segments
+    po_rel, sp_rel = np.asarray([5, 3, 5, 9]), np.asarray([3, 3, 7, 5, 3])
+    po_obj, sp_subj = np.asarray([40, 41, 40, 42]), np.asarray([43, 41, 44, 45, 40])
+    sg = make_row_segments(po_rel, po_obj, sp_subj, sp_rel, "cpu", min_rows=1, min_rows_per_relation=1.0)
+    order, seg = sg.rel
+    rel = np.concatenate([po_rel, sp_rel])
+    assert order.dtype == torch.int32 and seg.tolist() == [0, 4, 7, 8, 9]
+    assert order.tolist() == [1, 4, 5, 8, 0, 2, 7, 6, 3]                      # stable: rows ascending inside a relation
+    assert [sorted(set(rel[order[a:b].numpy()].tolist())) for a, b in zip(seg[:-1].tolist(), seg[1:].tolist())] == [[3], [5], [7], [9]]
+    e_order, e_seg = sg.ent
+    assert e_order.tolist() == [0, 2, 8, 1, 5, 3, 4, 6, 7] and e_seg.tolist() == [0, 3, 5, 6, 7, 8, 9]
+    # relations that hardly repeat keep their atomics, the entity plan stays; small batches get no plan at all
+    sg2 = make_row_segments(po_rel, po_obj, sp_subj, sp_rel, "cpu", min_rows=1, min_rows_per_relation=4.0)
+    assert sg2.rel is None and sg2.ent is not None
+    assert make_row_segments(po_rel, po_obj, sp_subj, sp_rel, "cpu") is None
+    assert make_row_segments(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), "cpu", min_rows=0) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scorer,d,n_rel,which", [("complex", 200, 12, "both"), ("distmult", 100, 7, "both"), ("complex", 256, 40, "rel"),
+                                                  ("complex", 64, 9, "ent")])
+def test_prefix_backward_segmented_equals_atomics(okge_lib, scorer, d, n_rel, which):
+    """okge_prefix_backward_segmented (gradient rows stored, one workgroup per relation / entity adds them up in the plan's
+    order, one read-modify-write per table row) == okge_prefix_backward (float atomics): same dE, dR to rounding; bit-reproducible;
+    entity rows of ANOTHER shard are left alone"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.sharded import RowSegments, make_row_segments
+    hp = H.HotPath("cuda:0")
+    rng = np.random.default_rng(d + n_rel)
+    n_ent, n_po, n_sp = 500, 190, 150
+    lo, hi = 100, 400                                                       # this "rank" owns entity ids [100, 400)
+    Efull = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    E = torch.from_numpy(Efull[lo:hi].copy()).cuda()
+    R = torch.from_numpy((rng.standard_normal((n_rel, d)) * 0.3).astype(np.float32)).cuda()
+    ids = dict(po_rel=rng.integers(2, n_rel, n_po).astype(np.int32), po_obj=rng.integers(2, 60, n_po).astype(np.int32) * 8,
+               sp_subj=rng.integers(2, 60, n_sp).astype(np.int32) * 8, sp_rel=rng.integers(2, n_rel, n_sp).astype(np.int32))
+    t = lambda a: torch.from_numpy(a).cuda()      # noqa: E731
+    batch = H.PrefixBatch(po_rel=t(ids["po_rel"]), po_obj=t(ids["po_obj"]), sp_subj=t(ids["sp_subj"]), sp_rel=t(ids["sp_rel"]))
+    batch.drop_po_ent, batch.drop_sp_ent = H.DropoutSpec(0.3, 5, H.STREAM_PO_ENT, 2), H.DropoutSpec(0.3, 5, H.STREAM_SP_ENT, 2)
+    batch.drop_po_rel, batch.drop_sp_rel = H.DropoutSpec(0.2, 5, H.STREAM_PO_REL, 2), H.DropoutSpec(0.2, 5, H.STREAM_SP_REL, 2)
+    shard = H.Shard(lo, hi, 0)
+    # the masked entity rows of ALL prefixes (what exchange 1 delivers): from a whole-table encode
+    whole = H.Shard(0, n_ent, 0)
+    er = hp.encode_entity_rows(torch.from_numpy(Efull).cuda(), R, scorer, batch, whole)
+    dq = torch.from_numpy(rng.standard_normal(tuple(er.shape)).astype(np.float32)).cuda()
+    sg = make_row_segments(ids["po_rel"], ids["po_obj"], ids["sp_subj"], ids["sp_rel"], "cuda:0", min_rows=1)
+    assert sg.rel is not None and sg.ent is not None
+    plan = {"both": sg, "rel": RowSegments(rel=sg.rel), "ent": RowSegments(ent=sg.ent)}[which]
+    out = []
+    for use in (None, plan, plan):
+        dE, dR = torch.full_like(E, -0.5), torch.full_like(R, 0.25)           # (both accumulate onto what is there)
+        hp.prefix_backward(E, R, scorer, batch, shard, dq, er, dE, dR, rel_segments=use)
+        torch.cuda.synchronize()
+        out.append((dE.cpu().numpy(), dR.cpu().numpy()))
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=0, atol=2e-6 * np.abs(out[0][1]).max())
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=0, atol=2e-6 * np.abs(out[0][0]).max())
+    if which != "ent":
+        np.testing.assert_array_equal(out[1][1], out[2][1])                  # fixed summation order: bit-reproducible
+    if which != "rel":
+        np.testing.assert_array_equal(out[1][0], out[2][0])
+    assert np.abs(out[0][1] - 0.25).max() > 1e-3 and (out[0][1][:2] == 0.25).all()      # reserved relation rows untouched
+    touched = np.unique(np.concatenate([ids["po_obj"], ids["sp_subj"]]))
+    owned = touched[(touched >= lo) & (touched < hi)] - lo
+    assert len(owned) > 5 and len(owned) < len(touched)                       # some prefixes live on other "ranks"
+    mask = np.zeros(hi - lo, bool)
+    mask[owned] = True
+    assert (out[1][0][~mask] == -0.5).all() and (np.abs(out[1][0][mask] + 0.5).max(axis=1) > 0).all()
 
 
 def test_exchange_plan():

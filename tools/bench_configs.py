@@ -73,12 +73,15 @@ def rank_shape(world, dev, t):
     sE, sR = torch.zeros_like(Et), torch.zeros_like(Rt)
     loss = torch.zeros(1, dtype=torch.float64, device=dev)
 
+    from open_knowledge_graph_embeddings_amd.sharded import make_row_segments
+    segs = make_row_segments(hb["po_rel"], hb["po_obj"], hb["sp_subj"], hb["sp_rel"], dev) if os.environ.get("OKGE_ROW_SEGMENTS", "1") == "1" else None
+
     def one():
         qe = eng.encode_queries(Et, Rt, w.scorer, batch, shard)
         dq = torch.empty_like(qe[0])
         eng.train_tiles(Et, Rt, w.scorer, qe[0], local, shard, dE, dq, w.N, normalizer=float(wg.B) * w.N, loss_out=loss,
                         grads_zero=True)
-        eng.prefix_backward(Et, Rt, w.scorer, batch, shard, dq, qe[1], dE, dR)
+        eng.prefix_backward(Et, Rt, w.scorer, batch, shard, dq, qe[1], dE, dR, rel_segments=segs)
         eng.adagrad2(Et, dE, sE, Rt, dR, sR, w.lr)
     for _ in range(5):
         one()
