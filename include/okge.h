@@ -249,6 +249,27 @@ typedef struct okge_token_embedder {
     float bn_eps, bn_momentum;
 } okge_token_embedder;
 
+/* One _encode call of a BATCH of calls.  A training step of the token-pooled models makes five (candidates, po relations,
+ * po objects, sp subjects, sp relations: trainer.py:75-91); issued one by one they are 35 small launches per step, as a
+ * batch three forward + three backward, each filling the chip.  Batch-norm statistics stay PER CALL; running statistics
+ * (forward) and parameter gradients (backward) are updated in the order of the array -- the reference's calls update one
+ * module's buffers in sequence.  Forward uses e, ids / first_id, n (> 0), raw, out, ld, saved; backward also d_out, dW,
+ * d_bn_weight, d_bn_bias (raw and saved as the forward left them).  Workspace: the sum of okge_pool_workspace_bytes(n, d)
+ * over the calls. */
+typedef struct okge_pool_call {
+    const okge_token_embedder *e;
+    const int32_t *ids;
+    int32_t first_id, n;
+    float *raw, *out;
+    int64_t ld;
+    float *saved;
+    const float *d_out;
+    float *dW, *d_bn_weight, *d_bn_bias;
+} okge_pool_call;
+int okge_pool_encode_calls(const okge_pool_call *calls, int32_t n_calls, int32_t training, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int okge_pool_backward_calls(const okge_pool_call *calls, int32_t n_calls, void *workspace, size_t workspace_bytes,
+                             void *stream);
 size_t okge_pool_workspace_bytes(int32_t n, int32_t d);
 int okge_pool_encode(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n, int32_t training,
                      float *raw, float *out, int64_t ld, float *saved, void *workspace, size_t workspace_bytes,

@@ -781,43 +781,84 @@ static int check_token_embedder(const okge_token_embedder *e, const int32_t *ids
 
 size_t okge_pool_workspace_bytes(int32_t n, int32_t d) { return n > 0 && d > 0 ? pool_workspace_bytes(n, d) : 0; }
 
+// one okge_pool_call -> the kernels' descriptor; `partial` = this call's share of the workspace
+static int pool_call_dev(const okge_pool_call &c, bool backward, bool training, char *&ws, size_t &ws_left, PoolCall &q)
+{
+    const okge_token_embedder *e = c.e;
+    if (int rc = check_token_embedder(e, c.ids, c.first_id, c.n)) return rc;
+    if (c.n <= 0) return fail(OKGE_ERR_INVALID, "a pooled call needs n > 0 (leave empty calls out of the batch)");
+    if (!c.raw || c.ld < e->d) return fail(OKGE_ERR_INVALID, "bad row block");
+    const bool bn = e->bn_weight != nullptr;
+    std::memset(&q, 0, sizeof(q));
+    q.W = e->W; q.tokens = e->token_ids; q.ids = c.ids; q.raw = c.raw; q.out = c.out; q.ld = c.ld;
+    q.d = e->d; q.L = e->max_len; q.first_id = c.first_id; q.n = c.n; q.pool = e->pool; q.n_ids = e->n_ids;
+    q.eps = e->bn_eps; q.momentum = e->bn_momentum;
+    q.bn_weight = e->bn_weight; q.bn_bias = e->bn_bias; q.run_mean = e->bn_running_mean; q.run_var = e->bn_running_var;
+    if (!backward) {
+        if (!c.out) return fail(OKGE_ERR_INVALID, "bad output rows");
+        if (bn && c.out == c.raw)
+            return fail(OKGE_ERR_INVALID, "with batch-norm the raw pooled rows are kept for backward: out must differ from raw");
+        if (bn && training && !c.saved)
+            return fail(OKGE_ERR_INVALID, "training-mode batch-norm needs the saved-statistics buffer (4*d floats)");
+        q.saved = bn && training ? c.saved : nullptr;
+    } else {
+        if (!c.d_out || !c.dW) return fail(OKGE_ERR_INVALID, "bad backward arguments");
+        if (bn && (!c.saved || !c.d_bn_weight || !c.d_bn_bias))
+            return fail(OKGE_ERR_INVALID, "batch-norm backward needs saved statistics and gradient buffers");
+        q.saved = bn ? c.saved : nullptr;
+        q.dY = c.d_out; q.dW = c.dW; q.d_weight = c.d_bn_weight; q.d_bias = c.d_bn_bias;
+    }
+    if (q.saved) {
+        const size_t need = pool_workspace_bytes(c.n, e->d);
+        if (!ws || ws_left < need) return fail(OKGE_ERR_WORKSPACE, "workspace too small (sum of okge_pool_workspace_bytes over the calls)");
+        q.partial = reinterpret_cast<float *>(ws);
+        ws += need;
+        ws_left -= need;
+    }
+    return OKGE_OK;
+}
+
+int okge_pool_encode_calls(const okge_pool_call *calls, int32_t n_calls, int32_t training, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
+    if (!calls || n_calls <= 0 || n_calls > POOL_MAX_CALLS) return fail(OKGE_ERR_INVALID, "1 to 8 pooled calls per batch");
+    PoolCall q[POOL_MAX_CALLS];
+    char *ws = static_cast<char *>(workspace);
+    size_t left = workspace_bytes;
+    for (int i = 0; i < n_calls; ++i)
+        if (int rc = pool_call_dev(calls[i], false, training != 0, ws, left, q[i])) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("pool_encode", st);
+    hipError_t err = launch_pool_encode_calls(q, n_calls, training != 0, id_err_ptr(), st);
+    if (err != hipSuccess) return fail_hip(err, "pool_encode");
+    return OKGE_OK;
+}
+
+int okge_pool_backward_calls(const okge_pool_call *calls, int32_t n_calls, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!calls || n_calls <= 0 || n_calls > POOL_MAX_CALLS) return fail(OKGE_ERR_INVALID, "1 to 8 pooled calls per batch");
+    PoolCall q[POOL_MAX_CALLS];
+    char *ws = static_cast<char *>(workspace);
+    size_t left = workspace_bytes;
+    for (int i = 0; i < n_calls; ++i)
+        if (int rc = pool_call_dev(calls[i], true, true, ws, left, q[i])) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("pool_backward", st);
+    hipError_t err = launch_pool_backward_calls(q, n_calls, id_err_ptr(), st);
+    if (err != hipSuccess) return fail_hip(err, "pool_backward");
+    return OKGE_OK;
+}
+
 int okge_pool_encode(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n, int32_t training,
                      float *raw, float *out, int64_t ld, float *saved, void *workspace, size_t workspace_bytes,
                      void *stream)
 {
     if (int rc = check_token_embedder(e, ids, first_id, n)) return rc;
-    if (!raw || !out || ld < e->d) return fail(OKGE_ERR_INVALID, "bad output rows");
     if (n == 0) return OKGE_OK;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t err;
-    {
-        ScopedTimer tm("pool_rows", st);
-        err = launch_pool_rows(e->W, e->d, e->token_ids, e->max_len, ids, first_id, n, e->pool, raw, ld, e->n_ids, id_err_ptr(), st);
-        if (err != hipSuccess) return fail_hip(err, "pool_rows");
-    }
-    if (!e->bn_weight) {
-        if (out != raw) {
-            err = hipMemcpy2DAsync(out, ld * sizeof(float), raw, ld * sizeof(float), e->d * sizeof(float), n,
-                                   hipMemcpyDeviceToDevice, st);
-            if (err != hipSuccess) return fail_hip(err, "copy pooled rows");
-        }
-        return OKGE_OK;
-    }
-    if (out == raw) return fail(OKGE_ERR_INVALID, "with batch-norm the raw pooled rows are kept for backward: out must differ from raw");
-    ScopedTimer tm("batchnorm_forward", st);
-    if (training) {
-        if (!saved) return fail(OKGE_ERR_INVALID, "training-mode batch-norm needs the saved-statistics buffer (4*d floats)");
-        if (!workspace || workspace_bytes < pool_workspace_bytes(n, e->d)) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
-        err = launch_bn_stats(raw, ld, n, e->d, e->bn_eps, e->bn_momentum, saved, e->bn_running_mean, e->bn_running_var,
-                              static_cast<float *>(workspace), st);
-        if (err != hipSuccess) return fail_hip(err, "batchnorm statistics");
-        err = launch_bn_apply(raw, ld, n, e->d, saved, saved + e->d, 0, e->bn_eps, e->bn_weight, e->bn_bias, out, ld, st);
-    } else {
-        err = launch_bn_apply(raw, ld, n, e->d, e->bn_running_mean, e->bn_running_var, 1, e->bn_eps, e->bn_weight, e->bn_bias,
-                              out, ld, st);
-    }
-    if (err != hipSuccess) return fail_hip(err, "batchnorm apply");
-    return OKGE_OK;
+    okge_pool_call c;
+    std::memset(&c, 0, sizeof(c));
+    c.e = e; c.ids = ids; c.first_id = first_id; c.n = n; c.raw = raw; c.out = out; c.ld = ld; c.saved = saved;
+    return okge_pool_encode_calls(&c, 1, training, workspace, workspace_bytes, stream);
 }
 
 int okge_pool_backward(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n, const float *raw,
@@ -825,18 +866,12 @@ int okge_pool_backward(const okge_token_embedder *e, const int32_t *ids, int32_t
                        void *workspace, size_t workspace_bytes, void *stream)
 {
     if (int rc = check_token_embedder(e, ids, first_id, n)) return rc;
-    if (!raw || !d_out || !dW || ld < e->d) return fail(OKGE_ERR_INVALID, "bad backward arguments");
     if (n == 0) return OKGE_OK;
-    const bool bn = e->bn_weight != nullptr;
-    if (bn && (!saved || !d_bn_weight || !d_bn_bias)) return fail(OKGE_ERR_INVALID, "batch-norm backward needs saved statistics and gradient buffers");
-    if (bn && (!workspace || workspace_bytes < pool_workspace_bytes(n, e->d))) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    ScopedTimer tm("pool_backward", st);
-    hipError_t err = launch_pool_backward(e->W, e->d, e->token_ids, e->max_len, ids, first_id, n, e->pool, raw, ld, d_out, ld,
-                                          bn ? saved : nullptr, e->bn_weight, d_bn_weight, d_bn_bias, dW,
-                                          static_cast<float *>(workspace), e->n_ids, st);
-    if (err != hipSuccess) return fail_hip(err, "pool_backward");
-    return OKGE_OK;
+    okge_pool_call c;
+    std::memset(&c, 0, sizeof(c));
+    c.e = e; c.ids = ids; c.first_id = first_id; c.n = n; c.raw = const_cast<float *>(raw); c.ld = ld; c.saved = saved;
+    c.d_out = d_out; c.dW = dW; c.d_bn_weight = d_bn_weight; c.d_bn_bias = d_bn_bias;
+    return okge_pool_backward_calls(&c, 1, workspace, workspace_bytes, stream);
 }
 
 int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream)

@@ -131,17 +131,26 @@ hipError_t launch_merge_lse(const float *parts, int world, int B, float *out, hi
 // error text for okge_last_error(), shared by the translation units of the C ABI (defined in okge_api.hip)
 int report_error(int code, const std::string &msg);
 
+// token-pooled embedder (okge_pool.hip): one _encode call of a batch (UnigramPoolingRelationEmbedder._encode, model.py:762-786)
+constexpr int POOL_MAX_CALLS = 8;
+struct PoolCall {
+    const float   *W;                       // token table (vocab x d)
+    const int32_t *tokens;                  // (n_ids x L) token ids
+    const int32_t *ids;                     // rows of the call (or first_id + i)
+    float         *raw, *out;               // [n][ld] pooled rows / normalised rows (out == raw without batch-norm)
+    float         *saved;                   // [4 d] {mean, rstd, scratch, scratch} of this call; nullptr: no training-mode batch-norm
+    const float   *dY;                      // backward: [n][ld] gradient of `out`
+    const float   *bn_weight, *bn_bias;     // nullptr: no batch-norm
+    float         *run_mean, *run_var;
+    float         *d_weight, *d_bias, *dW;  // backward targets
+    float         *partial;                 // [ceil(n / 32)][2][d] scratch of this call
+    int64_t        ld;
+    int32_t        d, L, first_id, n, pool, n_ids;
+    float          eps, momentum;
+};
 size_t pool_workspace_bytes(int n, int d);
-hipError_t launch_pool_rows(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
-                            int pool, float *out, int64_t ld, int n_ids, int *id_err, hipStream_t st);
-hipError_t launch_bn_stats(const float *X, int64_t ldx, int n, int d, float eps, float momentum, float *saved,
-                           float *run_mean, float *run_var, float *partial, hipStream_t st);
-hipError_t launch_bn_apply(const float *X, int64_t ldx, int n, int d, const float *mean, const float *rstd_or_var, int is_var,
-                           float eps, const float *weight, const float *bias, float *Y, int64_t ldy, hipStream_t st);
-hipError_t launch_pool_backward(const float *W, int d, const int32_t *tokens, int L, const int32_t *ids, int first_id, int n,
-                                int pool, const float *X, int64_t ldx, const float *DY, int64_t lddy, float *saved,
-                                const float *weight, float *d_weight, float *d_bias, float *dW, float *partial, int n_ids,
-                                hipStream_t st);
+hipError_t launch_pool_encode_calls(const PoolCall *calls, int n_calls, int training, int *id_err, hipStream_t st);
+hipError_t launch_pool_backward_calls(const PoolCall *calls, int n_calls, int *id_err, hipStream_t st);
 hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
                             int cand_first, int exclusive, int grads_zero, float *dE, int64_t table_rows, int *id_err,
                             hipStream_t st);

@@ -116,6 +116,49 @@ class PoolEngine:
                                             self._stream()), "okge_pool_backward")
 
 
+    # -- a batch of _encode calls in one go (okge_pool_encode_calls / okge_pool_backward_calls) ----------------------
+    def _calls(self, calls, backward):
+        """calls: [(slot, ids, first_id, n, raw, out_or_d_out, saved)] with n > 0 -> (ctypes array, keep-alive list, workspace)"""
+        arr = (N.PoolCall * len(calls))()
+        keep, need = [], 0
+        for x, (slot, ids, first_id, n, raw, other, saved) in zip(arr, calls):
+            e = slot.c()
+            keep.append(e)
+            x.e = ctypes.pointer(e)
+            x.ids, x.first_id, x.n = None if ids is None else ids.data_ptr(), int(first_id), int(n)
+            x.raw, x.ld = raw.data_ptr(), raw.stride(0)
+            x.saved = None if saved is None else saved.data_ptr()
+            if backward:
+                x.d_out, x.dW = other.data_ptr(), slot.dW.data_ptr()
+                if slot.bn is not None:
+                    x.d_bn_weight, x.d_bn_bias = slot.d_bn[:slot.d].data_ptr(), slot.d_bn[slot.d:].data_ptr()
+            else:
+                x.out = other.data_ptr()
+            need += int(self.lib.okge_pool_workspace_bytes(int(n), slot.d))
+        if need > self._ws_bytes:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws_bytes = need
+        return arr, keep
+
+    def encode_calls(self, calls, training):
+        calls = [c for c in calls if c[3] > 0]
+        if not calls:
+            return
+        arr, keep = self._calls(calls, False)
+        N.check(self.lib.okge_pool_encode_calls(arr, len(calls), int(training), None if self._ws is None else self._ws.data_ptr(),
+                                                self._ws_bytes, self._stream()), "okge_pool_encode_calls")
+        del keep
+
+    def backward_calls(self, calls):
+        calls = [c for c in calls if c[3] > 0]
+        if not calls:
+            return
+        arr, keep = self._calls(calls, True)
+        N.check(self.lib.okge_pool_backward_calls(arr, len(calls), None if self._ws is None else self._ws.data_ptr(),
+                                                  self._ws_bytes, self._stream()), "okge_pool_backward_calls")
+        del keep
+
+
 def _i32(t, dev):
     return None if t is None else t.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
 
@@ -132,12 +175,8 @@ class TokenPooledTrainStep:
         self.device = entity.W.device
         self.engine = engine or H.HotPath(self.device)
         self.pool = PoolEngine(self.device)
-        # the relation slot's encode / backward calls run on a side stream next to the entity slot's: five chains of
-        # small latency-bound kernels per step, two independent slots (own workspace: the calls overlap).  Off under
-        # graph capture (GraphedTrainStep), where one stream keeps the capture simple.
-        self.pool_side = PoolEngine(self.device)
-        self.side = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self.overlap_slots = self.side is not None
+        # (rounds 1-2 ran the five encode / backward calls of a step one by one, the relation slot's on a side stream:
+        #  35 small launches; they now go to the library as ONE batch each way: three launches forward, three backward)
         self.loss_out = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.step_dev = None              # device step counter, attached by GraphedTrainStep
         self._rows = 0
@@ -221,26 +260,9 @@ class TokenPooledTrainStep:
                  (ent, _i32(batch.po_obj, dev), 0, n_po, EX[N_c:N_c + n_po], EV[N_c:N_c + n_po], dEV[N_c:N_c + n_po], sv[2] if bn_e else None),
                  (ent, _i32(batch.sp_subj, dev), 0, n_sp, EX[N_c + n_po:N_c + B], EV[N_c + n_po:N_c + B], dEV[N_c + n_po:N_c + B], sv[3] if bn_e else None),
                  (rel, _i32(batch.sp_rel, dev), 0, n_sp, RX[n_po:B], RV[n_po:B], dRV[n_po:B], sv[4] if bn_r else None)]
-        two = self.overlap_slots and not torch.cuda.is_current_stream_capturing()
-        main = torch.cuda.current_stream(dev) if two else None
-
-        def on_slots(fn):
-            """fn(engine, call) for the five calls: entity slot on the current stream, relation slot on the side stream"""
-            if not two:
-                for call in calls:
-                    fn(pe, call)
-                return
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                for call in calls:
-                    if call[0] is rel:
-                        fn(self.pool_side, call)
-            for call in calls:
-                if call[0] is ent:
-                    fn(pe, call)
-            main.wait_stream(self.side)
-
-        on_slots(lambda eng_, c_: eng_.encode(c_[0], c_[1], c_[2], c_[3], True, c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]))
+        # forward of all five calls: raw pooled rows -> EX / RX, batch-normed rows -> EV / RV (per-call statistics, running
+        # statistics updated in this order)
+        pe.encode_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]) for c_ in calls], True)
         EVt, RVt = (EV if bn_e else EX), (RV if bn_r else RX)
         # the fused step on the virtual tables: candidates are rows 0..N-1, prefix entities follow
         ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
@@ -254,7 +276,7 @@ class TokenPooledTrainStep:
         self.engine.forward_backward(EVt[:N_c + B], RVt[:B], self.scorer, vb, dEV[:N_c + B], dRV[:B], loss=self.loss,
                                      label_smoothing=self.label_smoothing, normalizer=normalizer, loss_out=self.loss_out,
                                      scores=scores, grads_zero=True)
-        on_slots(lambda eng_, c_: eng_.backward(c_[0], c_[1], c_[2], c_[3], c_[4], c_[6], c_[7]))
+        pe.backward_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[6], c_[7]) for c_ in calls])
         dEV[:N_c + B].zero_()
         dRV[:B].zero_()
         return self.loss_out
