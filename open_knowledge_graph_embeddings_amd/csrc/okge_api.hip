@@ -236,7 +236,8 @@ bool make_geometry(int B, int N, int d, Geometry &g)
         g.b_per_block = g.Bpad;
     }
     // dQ kernel: (batch block, candidate range) workgroups: 8-wave workgroups, one per CU (d <= 256), else 4-wave, two per CU
-    g.dq8 = g.KB <= 16 && env_int("OKGE_DQ8", 1) != 0;
+    // (slot sizes above 256: dq8k_kernel, 32-candidate chunks double-buffered; OKGE_DQ8K=0 selects dq_kernel<32>)
+    g.dq8 = (g.KB <= 16 && env_int("OKGE_DQ8", 1) != 0) || (g.KB == 32 && env_int("OKGE_DQ8K", 1) != 0);
     int ns = std::max(1, (g.dq8 ? 256 : 512) / bblks);
     if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
     ns = env_int("OKGE_DQ_SPLIT", ns);

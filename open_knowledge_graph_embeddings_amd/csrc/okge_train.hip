@@ -656,6 +656,84 @@ __global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
     }
 }
 
+// ---- dQ = G . C for slot sizes above 256 (KB = 32): 32-candidate chunks, double-buffered ------------------------------------
+// dq_kernel<32> keeps a 64-candidate tile (132 KB) + its G^T block in LDS, single-buffered: per chunk every wave parks 16
+// float4, the workgroup passes two barriers and waits for the next chunk's loads while the MFMA pipes idle -- 0.52 of the
+// fp32-MFMA peak at the DistMult d = 512 shape, and (one workgroup per CU but a grid sized for two) 64 candidate splits =
+// 64 MB of dQ slabs that the prefix backward reads back.  Here a chunk is 32 candidates: two (candidate tile, G^T tile) pairs
+// fit the LDS (2 x 66 KB + 2 x 8.5 KB), chunk ch + 1 is parked in the second pair while chunk ch is being multiplied -- ONE
+// barrier per chunk, no staging phase --, the two waves of a SIMD take turns (group ks = 0 parks before its MFMAs, group
+// ks = 1 after), and the candidate range of a workgroup is twice as long (32 splits: half the slabs).  Wave (wq = w & 3,
+// ks = w >> 2): batch rows 16 wq .., output columns 256 ks ..; contraction rows of slot s: candidates 8 s + t, t < 8.
+__global__ __launch_bounds__(512, 2) void dq8k_kernel(const DqArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KB = 32, LDK = lds_ld(16 * KB), NTHR = 512, NC = 32;            // NC candidates per chunk
+    constexpr int KBW = KB / 2, KQ = KBW / 4;
+    constexpr int PAIR = NC * LDK + NC * LDGT;        // floats of one (candidate tile, G^T tile) pair
+    float *Cs = reinterpret_cast<float *>(smem);      // [NC][LDK]
+    float *Gt = Cs + NC * LDK;                        // [NC (n)][LDGT]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c = lane & 15, s = lane >> 4;
+    const int wq = w & 3, ks = w >> 2;
+    const int split = blockIdx.x % a.nsplit, bblk = blockIdx.x / a.nsplit;
+    const int b0 = bblk * BC;
+    const int nJ = a.Bpad / BC;
+    const int nchunks = 2 * ((a.N + NT - 1) / NT);    // whole 64-candidate blocks: the tile kernel wrote all of their rows
+    const int ch_lo = (int)((int64_t)split * nchunks / a.nsplit);
+    const int ch_hi = (int)((int64_t)(split + 1) * nchunks / a.nsplit);
+
+    v4f acc[KBW];                                     // dQ[b = b0 + 16wq + 4s + i][k = 256 ks + grad_col(kbi, c)]
+#pragma unroll
+    for (int kb = 0; kb < KBW; ++kb) acc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = tid >> 4, q16 = tid & 15;         // staging: row r16 of the chunk, float4 columns q16 + 16 it
+    v4f gv, cv[8];
+    auto prefetch = [&](int ch) {
+        gv = *reinterpret_cast<const v4f *>(a.G + ((size_t)(ch >> 1) * nJ + bblk) * 4096 + (ch & 1) * 2048 + (size_t)tid * 4);
+        const float *cm = a.Cm + ((size_t)ch * NC + r16) * (16 * KB);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) cv[it] = *reinterpret_cast<const v4f *>(cm + 4 * (q16 + 16 * it));
+    };
+    auto park = [&](int buf) {
+        float *cs = Cs + buf * PAIR, *gt = Gt + buf * PAIR;
+        *reinterpret_cast<v4f *>(gt + (tid >> 4) * LDGT + 4 * (tid & 15)) = gv;       // float4 number tid: candidate tid >> 4
+#pragma unroll
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<v4f *>(cs + r16 * LDK + 4 * (q16 + 16 * it)) = cv[it];
+    };
+    if (ch_lo < ch_hi) {
+        prefetch(ch_lo);
+        park(0);
+        if (ch_lo + 1 < ch_hi) prefetch(ch_lo + 1);
+    }
+    for (int ch = ch_lo; ch < ch_hi; ++ch) {
+        const int buf = (ch - ch_lo) & 1;
+        __syncthreads();                       // chunk ch is parked; the other pair's readers (chunk ch - 1) are done
+        const bool more = ch + 1 < ch_hi;
+        if (ks == 0 && more) {                 // this wave group parks its share of chunk ch + 1 first ...
+            park(buf ^ 1);
+            if (ch + 2 < ch_hi) prefetch(ch + 2);
+        }
+        // A[i = b][slot s, step t] = G^T[n = 8s + t][b = 16wq + c] ; B[slot][k] = C[n = 8s + t][256 ks + k]
+        grad_product<KBW, false, LDK, 0, 8>(acc, Gt + buf * PAIR + 8 * s * LDGT + 16 * wq + c, LDGT,
+                                            Cs + buf * PAIR + 8 * s * LDK + 16 * KBW * ks, c);
+        if (ks == 1 && more) {                 // ... the other one after its MFMAs: a SIMD's two waves take turns
+            park(buf ^ 1);
+            if (ch + 2 < ch_hi) prefetch(ch + 2);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float *dst = a.slab + ((size_t)split * a.Bpad + b0 + 16 * wq + 4 * s + i) * a.ldq + 16 * KBW * ks;
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            v4f v = (v4f){acc[4 * kq][i], acc[4 * kq + 1][i], acc[4 * kq + 2][i], acc[4 * kq + 3][i]};
+            if (a.accumulate) v += *reinterpret_cast<const v4f *>(dst + 64 * kq + 4 * c);
+            *reinterpret_cast<v4f *>(dst + 64 * kq + 4 * c) = v;
+        }
+    }
+}
+
 // ---- host-side launchers -----------------------------------------------------------------------------
 template <int KB, int MODE>
 static hipError_t launch_fused_t(const FusedArgs &a, dim3 grid, size_t shmem, hipStream_t st)
@@ -737,6 +815,13 @@ hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st)
             case 16: return launch_dq8_t<16>(a, grid_x, shmem, st);
             default: break;
         }
+    }
+    if (a.waves8 && a.KB == 32) {
+        const size_t sh = (size_t)2 * (32 * lds_ld(512) + 32 * LDGT) * sizeof(float);
+        static LdsOptIn lds_opt_in;
+        if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(dq8k_kernel), sh); e != hipSuccess) return e;
+        hipLaunchKernelGGL(dq8k_kernel, dim3(grid_x), dim3(512), sh, st, a);
+        return hipGetLastError();
     }
     switch (a.KB) {
         case 4:  return launch_dq_t<4>(a, grid_x, shmem, st);
