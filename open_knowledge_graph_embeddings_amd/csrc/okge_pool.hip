@@ -19,6 +19,7 @@ namespace {
 constexpr int POOL_SUM = 0, POOL_MEAN = 1, POOL_MAX = 2;
 constexpr int STAT_ROWS = 32;          // rows per pooling / partial-sum workgroup
 constexpr int POOL_BWD_ROWS = 16, HOT_TOKENS = 32, POOL_MAX_LEN = 64;
+constexpr int BN_ROWS = 16;            // rows per workgroup of bn_apply_kernel
 
 // A step of the token-pooled models makes FIVE _encode calls (candidates, po relations, po objects, sp subjects, sp
 // relations: trainer.py:75-91) and as many backward passes.  Run one after the other they were 35 small launches per step,
@@ -264,12 +265,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const PoolBatch pb, int t
     }
     int lb;
     const PoolCall &q = pb.c[locate_call(pb, blockIdx.x, lb)];
-    const int64_t idx = (int64_t)lb * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)q.n * q.d) return;
-    const int i = (int)(idx / q.d), k = (int)(idx % q.d);
-    const float mean = training ? q.saved[k] : q.run_mean[k];
-    const float rs = training ? q.saved[q.d + k] : 1.0f / sqrtf(q.run_var[k] + q.eps);
-    q.out[(size_t)i * q.ld + k] = (q.raw[(size_t)i * q.ld + k] - mean) * rs * q.bn_weight[k] + q.bn_bias[k];
+    // a workgroup takes BN_ROWS rows; thread = column (quad): the per-column factors are loaded once per workgroup
+    const int d = q.d, r0 = lb * BN_ROWS, r1 = min(q.n, r0 + BN_ROWS);
+    const bool vec = (d & 3) == 0 && (q.ld & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(q.raw) | reinterpret_cast<uintptr_t>(q.out)) & 15) == 0;
+    if (vec) {
+        for (int k = 4 * threadIdx.x; k < d; k += 4 * blockDim.x) {
+            float rs[4], mu[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mu[e] = training ? q.saved[k + e] : q.run_mean[k + e];
+                rs[e] = training ? q.saved[d + k + e] : 1.0f / sqrtf(q.run_var[k + e] + q.eps);
+            }
+            const float4 wt = *reinterpret_cast<const float4 *>(q.bn_weight + k), bias = *reinterpret_cast<const float4 *>(q.bn_bias + k);
+            for (int i = r0; i < r1; ++i) {
+                const float4 x = *reinterpret_cast<const float4 *>(q.raw + (size_t)i * q.ld + k);
+                float4 o;                         // (x - mean) * rstd * weight + bias, the scalar path's order: same bits
+                o.x = (x.x - mu[0]) * rs[0] * wt.x + bias.x;
+                o.y = (x.y - mu[1]) * rs[1] * wt.y + bias.y;
+                o.z = (x.z - mu[2]) * rs[2] * wt.z + bias.z;
+                o.w = (x.w - mu[3]) * rs[3] * wt.w + bias.w;
+                *reinterpret_cast<float4 *>(q.out + (size_t)i * q.ld + k) = o;
+            }
+        }
+        return;
+    }
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        const float mean = training ? q.saved[k] : q.run_mean[k];
+        const float rs = training ? q.saved[d + k] : 1.0f / sqrtf(q.run_var[k] + q.eps);
+        for (int i = r0; i < r1; ++i)
+            q.out[(size_t)i * q.ld + k] = (q.raw[(size_t)i * q.ld + k] - mean) * rs * q.bn_weight[k] + q.bn_bias[k];
+    }
 }
 
 // dx = weight * rstd * (dy - dbias/n - xhat * dweight/n)   (or dx = dy without batch-norm), then scattered into the
@@ -415,7 +441,7 @@ hipError_t launch_pool_encode_calls(const PoolCall *calls, int n_calls, int trai
         const PoolBatch pf = make_batch(bn, nb, id_err, [](const PoolCall &q) { return (q.d + FIN_COLS - 1) / FIN_COLS; });
         hipLaunchKernelGGL(bn_finish_kernel<0>, dim3(pf.cum[nb]), dim3(256), 0, st, pf);
     }
-    const PoolBatch pa = make_batch(bn, nb, id_err, [](const PoolCall &q) { return (int)(((int64_t)q.n * q.d + 255) / 256); });
+    const PoolBatch pa = make_batch(bn, nb, id_err, [](const PoolCall &q) { return (q.n + BN_ROWS - 1) / BN_ROWS; });
     hipLaunchKernelGGL(bn_apply_kernel, dim3(pa.cum[nb] + (training ? 1 : 0)), dim3(256), 0, st, pa, training);
     return hipGetLastError();
 }

@@ -265,11 +265,17 @@ class TokenPooledTrainStep:
         pe.encode_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]) for c_ in calls], True)
         EVt, RVt = (EV if bn_e else EX), (RV if bn_r else RX)
         # the fused step on the virtual tables: candidates are rows 0..N-1, prefix entities follow
-        ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
+        # row indices of the virtual tables: they depend on the batch's shape only -- built once per shape (four arange
+        # launches per step otherwise: 18 us of a 0.9 ms step at configs[4])
+        key = (N_c, n_po, n_sp)
+        if getattr(self, "_ar_key", None) != key:
+            rng = torch.arange(0, N_c + B, dtype=torch.int32, device=dev)
+            self._ar_key, self._ar = key, (rng[:n_po], rng[N_c:N_c + n_po], rng[N_c + n_po:N_c + B], rng[n_po:B])
+        ar_po_rel, ar_po_obj, ar_sp_subj, ar_sp_rel = self._ar
         p, s, t = self.dropout, self.seed, self.steps
         DS = lambda stream: H.DropoutSpec(p, s, stream, t, step_dev=self.step_dev)      # noqa: E731
-        vb = H.PrefixBatch(po_rel=ar(0, n_po) if n_po else None, po_obj=ar(N_c, N_c + n_po) if n_po else None,
-                           sp_subj=ar(N_c + n_po, N_c + B) if n_sp else None, sp_rel=ar(n_po, B) if n_sp else None,
+        vb = H.PrefixBatch(po_rel=ar_po_rel if n_po else None, po_obj=ar_po_obj if n_po else None,
+                           sp_subj=ar_sp_subj if n_sp else None, sp_rel=ar_sp_rel if n_sp else None,
                            pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=N_c,
                            drop_cand=DS(H.STREAM_CAND), drop_po_ent=DS(H.STREAM_PO_ENT), drop_sp_ent=DS(H.STREAM_SP_ENT),
                            drop_po_rel=DS(H.STREAM_PO_REL), drop_sp_rel=DS(H.STREAM_SP_REL))
@@ -277,7 +283,7 @@ class TokenPooledTrainStep:
                                      label_smoothing=self.label_smoothing, normalizer=normalizer, loss_out=self.loss_out,
                                      scores=scores, grads_zero=True)
         pe.backward_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[6], c_[7]) for c_ in calls])
-        dEV[:N_c + B].zero_()
+        dEV[N_c:N_c + B].zero_()         # (the candidate rows are STORED by the next step's tile kernel: grads_zero)
         dRV[:B].zero_()
         return self.loss_out
 
