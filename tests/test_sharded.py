@@ -560,6 +560,16 @@ def test_three_phase_abi_emulated_shards(world, loss, okge_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,loss,d", [(2, "bce", 320), (3, "kl", 512)])
+def test_three_phase_abi_emulated_shards_wide_slots(world, loss, d, okge_lib, monkeypatch):
+    """the same three phases at slot sizes above 256: the register-tile kernel (stream-K launch, shard-relative candidate
+    columns for the Philox keys and the positives) and the 32-candidate-chunk dQ kernel inside okge_train_tiles"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "D", d)
+    test_three_phase_abi_emulated_shards(world, loss, okge_lib)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_ranks_emulated_shards(world, okge_lib):
     """score_queries + group_true_scores ("all-reduce max") + rank_counts ("all-reduce sum") over emulated shards
