@@ -298,6 +298,18 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
 }
 
 
+// the score sweep (MODE_SCORE) of `tiles` 64-candidate tiles over all B rows: the 64 x 64 kernel up to slot size 256; above, the
+// register-tile kernel in a stream-K launch (rows are independent: no partial outputs to add up), or the 32 x 32 cut it replaced
+hipError_t launch_score_sweep(const Geometry &g, const FusedArgs &a0, int tiles, hipStream_t st)
+{
+    if (g.KB <= 16) return launch_fused(MODE_SCORE, a0, tiles, 1, st);
+    if (g.tile_w == 32) return launch_fused32(MODE_SCORE, a0, 2 * tiles, 1, st);
+    FusedArgs a = a0;
+    a.sk_tiles = tiles;
+    const int64_t units = (int64_t)tiles * ((a.B + 31) / 32);
+    return launch_fused64k(MODE_SCORE, a, (int)std::min<int64_t>(std::min(cu_count(), 511), units), 1, st);
+}
+
 // Arguments of candidate range r (geometry: ranges of g.range_n candidates): local candidate 0 of the launch is
 // candidate r * range_n of the call.  Positives / dropout keep their global columns through cand_col0.
 FusedArgs range_args(const FusedArgs &base, const Geometry &g, int r, int &tiles_r)
@@ -398,8 +410,7 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
     a.b_per_block = g.Bpad;     // rows are independent in score mode, but one pass per tile keeps C resident
     {
         ScopedTimer tm("fused_tile_score", st);
-        hipError_t e = g.KB <= 16 ? launch_fused(MODE_SCORE, a, g.tiles, 1, st)        // 64x64 cut
-                                  : launch_fused32(MODE_SCORE, a, 2 * g.tiles, 1, st);    // slot sizes above 256
+        hipError_t e = launch_score_sweep(g, a, g.tiles, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     return OKGE_OK;
@@ -472,7 +483,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         s.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
         s.b_per_block = g.Bpad;
         ScopedTimer tm("fused_tile_score", st);
-        e = g.KB <= 16 ? launch_fused(MODE_SCORE, s, g.tiles, 1, st) : launch_fused32(MODE_SCORE, s, 2 * g.tiles, 1, st);
+        e = launch_score_sweep(g, s, g.tiles, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     }
     if (loss_kind == OKGE_LOSS_KL) {
@@ -666,7 +677,7 @@ int okge_score_queries(const okge_tables *t, const okge_shard *sh, const float *
     a.x_vec_ok = (ld_scores % 4 == 0) && (reinterpret_cast<uintptr_t>(scores) % 16 == 0);
     a.b_per_block = g.Bpad;
     ScopedTimer tm("fused_tile_score", st);
-    hipError_t e = g.KB <= 16 ? launch_fused(MODE_SCORE, a, g.tiles, 1, st) : launch_fused32(MODE_SCORE, a, 2 * g.tiles, 1, st);
+    hipError_t e = launch_score_sweep(g, a, g.tiles, st);
     if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<score>");
     return OKGE_OK;
 }

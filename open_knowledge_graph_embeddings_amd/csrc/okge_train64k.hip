@@ -62,7 +62,8 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
     constexpr int D16 = 16 * KB, KH = 16 * KBW;                 // padded slot size, columns of one half
     constexpr int NQ = 4 * KB, QG = 16, NQIT = NQ / QG;         // float4 per row; staging: 16 column groups per row
     static_assert(KB % 8 == 0, "the column split needs whole quads of 16-column blocks per wave");
-    static_assert(MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL, "training kernel");
+    static_assert(MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL || MODE == MODE_SCORE, "training kernel, or the score sweep");
+    constexpr bool TRAIN = MODE != MODE_SCORE;           // MODE_SCORE: the same sweep stops after the score blocks and writes X
     const int d = a.d;
     float *Qb = reinterpret_cast<float *>(smem);                              // [2][32][LDK]  (end: [64][LDK] gradient stage)
     v4f *xs = reinterpret_cast<v4f *>(Qb + 2 * BCK * LDK);                    // [8 waves][2 row groups][64 lanes]
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
     };
     fetch_chunk(b_begin);
 
-    const int pos_lo = a.tile_ptr[tile], pos_hi = a.tile_ptr[tile + 1];
+    const int pos_lo = TRAIN ? a.tile_ptr[tile] : 0, pos_hi = TRAIN ? a.tile_ptr[tile + 1] : 0;
     const int pos_cached = min(pos_hi - pos_lo, POS_CACHE);
 
     // ---- candidate operand: lane (c, s) of wave (blk, ks) keeps C[16 blk + c][256 ks + 16 r + 4 s .. + 3], r < KBW ----------
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
                 const int r = 2 * j + (s & 1);                                   // the rounds this lane computes
                 const int o = (KH * ks + 16 * r + 4 * s) >> 3;
                 mine[j] = (valid && 8 * o < d) ? drop_keep8<true>(a.drop_c, (uint32_t)(n + a.cand_col0), o, d, dstep) : 0u;
-                keepb[nl * KEEP_LD + o] = (uint8_t)mine[j];
+                if (TRAIN) keepb[nl * KEEP_LD + o] = (uint8_t)mine[j];
             }
 #pragma unroll
             for (int j = 0; j < KBW / 2; ++j) {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
             }
         }
         const float sc = a.drop_c.enabled ? a.drop_c.scale : 1.f;
-        float *cm = (first_rows && !a.loss_only) ? a.Cm + (size_t)n * D16 + KH * ks + 4 * s : nullptr;
+        float *cm = (TRAIN && first_rows && !a.loss_only) ? a.Cm + (size_t)n * D16 + KH * ks + 4 * s : nullptr;
 #pragma unroll
         for (int r = 0; r < KBW; ++r) {
             const int k = KH * ks + 16 * r + 4 * s;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
             if (row >= 0 && row < BCK) atomicOr(&yb[BCK * (col >> 5) + row], 1u << (col & 31));
         }
     };
-    set_label_bits(b_begin, ybits3);     // (chunk 0: set after the clear above, read after the chunk's mid barrier)
+    if (TRAIN) set_label_bits(b_begin, ybits3);     // (chunk 0: set after the clear above, read after the chunk's mid barrier)
 
     int par = 0, buf = 0;
     for (int b0 = b_begin; b0 < b_end; b0 += BCK, par = par == 2 ? 0 : par + 1, buf ^= 1) {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
         const float *Qc = Qb + buf * (BCK * LDK);
         float *Qn = Qb + (buf ^ 1) * (BCK * LDK);
         if (b0 > b_begin) __syncthreads();   // chunk parked by everyone (during the previous chunk); the other buffer is free
-        {   // under the score product: the next chunk's label bits, the buffer after that cleared
+        if (TRAIN) {   // under the score product: the next chunk's label bits, the buffer after that cleared
             const int pn = par == 2 ? 0 : par + 1, pc = pn == 2 ? 0 : pn + 1;
             if (tid < 2 * BCK) ybits3[pc * (2 * BCK) + tid] = 0u;
             if (b0 + BCK < b_end) set_label_bits(b0 + BCK, ybits3 + pn * (2 * BCK));
@@ -265,6 +266,21 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
         __syncthreads();
         x0 += xs[((w ^ 4) * 2 + 0) * 64 + lane];             // a + b == b + a: both partners hold the same bits
         x1 += xs[((w ^ 4) * 2 + 1) * 64 + lane];
+        if (MODE == MODE_SCORE) {
+            // scores out: partner ks takes row group ks (rows 16 ks + 4 s + i, candidate 16 blk + c: 64-byte runs per row)
+            const v4f x = ks == 0 ? x0 : x1;
+            const int n = n0 + 16 * blk + c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + 16 * ks + 4 * s + i;
+                if (b < b_end && n < a.N) a.X[(size_t)b * a.ldx + n] = x[i];
+            }
+            if (b0 + BCK < b_end) {
+                park_chunk(Qn);
+                if (b0 + 2 * BCK < b_end) fetch_chunk(b0 + 2 * BCK);
+            }
+            continue;
+        }
 
         // B operands (query rows) of the dC product's first step: requested now, consumed after the epilogue
         const float *qb = Qc + (4 * s) * LDK + KH * ks + 4 * c;
@@ -344,6 +360,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
             }
         }
     }
+    if (!TRAIN) continue;
     __syncthreads();
 
     // ---- write-back: every wave stages ITS (16 candidates x 256 columns) of dC into LDS (the two chunk buffers are one
@@ -407,6 +424,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
     }
     }   // segments
 
+    if (!TRAIN) return;
     // ---- this workgroup's loss partial (all its segments; the ks == 0 partner of every pair counted) -------------------------
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     {
@@ -442,11 +460,13 @@ static hipError_t launch64k_t(const FusedArgs &a, dim3 grid, hipStream_t st)
     return hipGetLastError();
 }
 
-// grid_x = number of 64-candidate tiles, slot sizes above 256 (KB = 32)
+// grid_x = number of 64-candidate tiles (or workgroups of a stream-K launch), slot sizes above 256 (KB = 32); MODE_SCORE: the
+// score sweep of okge_score_prefixes / okge_score_queries / `all_outputs` on the same layout
 hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st)
 {
-    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL) || a.KB != 32) return hipErrorInvalidValue;
+    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL && mode != MODE_SCORE) || a.KB != 32) return hipErrorInvalidValue;
     const dim3 grid(grid_x, grid_y);
+    if (mode == MODE_SCORE) return launch64k_t<32, MODE_SCORE>(a, grid, st);
     return mode == MODE_TRAIN_KL ? launch64k_t<32, MODE_TRAIN_KL>(a, grid, st) : launch64k_t<32, MODE_TRAIN_BCE>(a, grid, st);
 }
 
