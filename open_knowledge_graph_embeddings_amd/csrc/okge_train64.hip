@@ -587,7 +587,8 @@ hipError_t launch_fused64(int mode, const FusedArgs &a, int grid_x, int grid_y, 
         case 4:  return launch64_m<4>(mode, a, grid, st);
         case 8:  return launch64_m<8>(mode, a, grid, st);
         case 13: return launch64_m<13>(mode, a, grid, st);
-        case 16: return launch64_m<16>(mode, a, grid, st);
+        case 16: { static const bool k64 = [] { const char *e = getenv("OKGE_TILE64K_D256"); return e && atoi(e) != 0; }();
+                   return k64 ? launch_fused64k(mode, a, grid_x, grid_y, st) : launch64_m<16>(mode, a, grid, st); }
         case 32: return launch_fused64k(mode, a, grid_x, grid_y, st);      // okge_train64k.hip
         default: return hipErrorInvalidValue;
     }

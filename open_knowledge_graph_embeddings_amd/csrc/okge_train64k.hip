@@ -464,8 +464,10 @@ static hipError_t launch64k_t(const FusedArgs &a, dim3 grid, hipStream_t st)
 // score sweep of okge_score_prefixes / okge_score_queries / `all_outputs` on the same layout
 hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st)
 {
-    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL && mode != MODE_SCORE) || a.KB != 32) return hipErrorInvalidValue;
     const dim3 grid(grid_x, grid_y);
+    if (a.KB == 16 && (mode == MODE_TRAIN_BCE || mode == MODE_TRAIN_KL))      // experiment (OKGE_TILE64K_D256=1): d <= 256 on this layout
+        return mode == MODE_TRAIN_KL ? launch64k_t<16, MODE_TRAIN_KL>(a, grid, st) : launch64k_t<16, MODE_TRAIN_BCE>(a, grid, st);
+    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL && mode != MODE_SCORE) || a.KB != 32) return hipErrorInvalidValue;
     if (mode == MODE_SCORE) return launch64k_t<32, MODE_SCORE>(a, grid, st);
     return mode == MODE_TRAIN_KL ? launch64k_t<32, MODE_TRAIN_KL>(a, grid, st) : launch64k_t<32, MODE_TRAIN_BCE>(a, grid, st);
 }
