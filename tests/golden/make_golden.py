@@ -39,6 +39,8 @@ Vectors:
                   evaluation slice of the trained tables (scores, per-group ranks, MRR / MR / Hits)
   g12_variant_*   LookupComplexRelationModel with batch_norm / project_entity / normalize='norm' / l2_reg on
                   (model.py:463-479): loss, hook loss, outputs, every parameter's gradient, running stats, eval scores
+  g14_distmult    configs[2] at its size: the reference's LookupDistmultRelationModel d = 512 on a real FB15k-237 batch that its
+                  collate built with batch-shared sampled candidates (N = 10 000): loss, score slice, gradient checksums
   g13_valid_pass  reference-trained tables (rounded to bf16, stored 16-bit) + the reference's evaluation over ALL of
                   FB15k-237 valid.txt (its loader, collate, eval-mode AddLossModule, compute_metrics): per-group ranks, meters
   g11_traj_*      30 training steps at the BASELINE size on real FB15k-237 batches (reference dataset + collate), then
@@ -893,6 +895,67 @@ def g13():
 
 
 # ----------------------------------------------------------------------------------------------
+# G14: BASELINE configs[2] at its size through the reference: LookupDistmultRelationModel d = 512, batch-shared sampled candidates
+# ----------------------------------------------------------------------------------------------
+def g14():
+    """512 prefixes of FB15k-237 (test.txt standing in for the absent train split) collated by the reference with
+    use_batch_shared_entities=True, min_size_batch_labels=10000 (numpy-sampled fill-up negatives, dataset.py:853-860), then
+    AddLossModule (bce) forward + (loss / normalizer).backward() of the reference's LookupDistmultRelationModel d = 512.
+    Stored: prefix ids, the 10 000 candidate ids, label coordinates, loss, a score slice + per-row score sums, gradient
+    checksums + slices.  The tables are regenerated from the seed by the test (checksums guard them)."""
+    import shutil
+    import tempfile
+    from openkge.dataset import OneToNMentionRelationDataset_collate_func as collate
+    fb = "/root/reference/data/fb15k237/mapped_to_ids"
+    scratch = tempfile.mkdtemp(prefix="okge_g14_")
+    try:
+        for f in os.listdir(fb):
+            shutil.copy(os.path.join(fb, f), scratch)
+        files = {"train": "test.txt", "valid": "valid.txt", "test": "test.txt"}
+        tr = OneToNMentionRelationDataset(dataset_dir=scratch, input_file=files["train"], is_training_data=True, batch_size=512,
+                                          copy_data_to_dev_shm=False)
+        OneToNMentionRelationDataset(dataset_dir=scratch, input_file=files["valid"], is_training_data=False, batch_size=512,
+                                     copy_data_to_dev_shm=False)          # (writes the valid split's prefix files the merge reads)
+        tr.merge_all_splits_triples(dataset_dir=scratch, train_input_file=files["train"], valid_input_file=files["valid"],
+                                    test_input_file=files["test"])
+        tr.create_data_tensors(dataset_dir=scratch, train_input_file=files["train"], valid_input_file=files["valid"],
+                               test_input_file=files["test"])
+        n_ent, n_rel = tr.entity_vocab_size, tr.relations_size
+        pref = tr.seen_prefixes_tensor
+        slot = pref[:, 6]
+        rows = torch.cat([torch.nonzero(slot == 0).view(-1)[1000:1256], torch.nonzero(slot == 2).view(-1)[2000:2256]])
+        np.random.seed(1414)
+        out = collate(use_batch_shared_entities=True, sp_po__batch=[pref[i] for i in rows.tolist()], entity_vocab_size=n_ent,
+                      entity_vocab_offset=2, is_training_data=True, this_split_entities_list=tr.seen_entities_tensor,
+                      all_splits_entities_tensor=tr.all_splits_entities_tensor, min_size_batch_labels=10000)
+        inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = out
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    assert cand.numel() == 10000 and labels.shape == (512, 10000)
+    seed, d = 2027, 512
+    m = make_model("LookupDistmultRelationModel", n_ent, n_rel, d, seed=seed, init_std=0.1)
+    E, R = npy(m.entity_embedding.weight).copy(), npy(m.relation_embedding.weight).copy()
+    m.train()
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+    mod.train()
+    loss, _, outputs = mod(inputs=list(inputs), labels=labels.clone(), use_batch_shared_entities=True,
+                           batch_shared_entities=cand, epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+    (loss.sum() / float(norm_loss)).backward()
+    dE, dR = npy(m.entity_embedding.weight.grad), npy(m.relation_embedding.weight.grad)
+    x = outputs.detach()
+    save("g14_distmult_d512_sampled", seed=np.int64(seed), n_ent=np.int64(n_ent), n_rel=np.int64(n_rel), d=np.int64(d),
+         table_check=np.asarray([E.sum(dtype=np.float64), np.abs(E).sum(dtype=np.float64), R.sum(dtype=np.float64),
+                                 float(E[5, 7]), float(E[-1, -1]), float(R[3, 4])], np.float64),
+         po_rel=npy(inputs[0][0]).reshape(-1), po_obj=npy(inputs[0][1]).reshape(-1), sp_subj=npy(inputs[1][0]).reshape(-1),
+         sp_rel=npy(inputs[1][1]).reshape(-1), cand=npy(cand).reshape(-1).astype(np.int32),
+         labels=npy(labels.nonzero()).astype(np.int32), loss=np.float64(loss.item()), normalizer=np.float64(norm_loss),
+         n_labels=np.float64(norm_metric), score_slice=npy(x[192:320, 4000:4128]), score_row_sum=npy(x.double().sum(1)),
+         score_row_absmax=npy(x.abs().max(1).values), dE_row_sum=dE.astype(np.float64).sum(1),
+         dE_abs_sum=np.float64(np.abs(dE).sum(dtype=np.float64)), dE_slice=dE[npy(cand).reshape(-1)[:64].astype(np.int64), :16].copy(),
+         dR_row_sum=dR.astype(np.float64).sum(1), dR_slice=dR[:32, :64].copy())
+
+
+# ----------------------------------------------------------------------------------------------
 # G12: embedder variants of the lookup models (batch-norm, entity projection, normalisation, l2_reg hook)
 # ----------------------------------------------------------------------------------------------
 def g12():
@@ -992,7 +1055,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
         if not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)
