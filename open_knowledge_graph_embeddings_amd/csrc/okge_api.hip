@@ -300,14 +300,14 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
 
 // the score sweep (MODE_SCORE) of `tiles` 64-candidate tiles over all B rows: the 64 x 64 kernel up to slot size 256; above, the
 // register-tile kernel in a stream-K launch (rows are independent: no partial outputs to add up), or the 32 x 32 cut it replaced
-hipError_t launch_score_sweep(const Geometry &g, const FusedArgs &a0, int tiles, hipStream_t st)
+hipError_t launch_score_sweep(const Geometry &g, const FusedArgs &a0, int tiles, hipStream_t st, int mode = MODE_SCORE)
 {
-    if (g.KB <= 16) return launch_fused(MODE_SCORE, a0, tiles, 1, st);
-    if (g.tile_w == 32) return launch_fused32(MODE_SCORE, a0, 2 * tiles, 1, st);
+    if (g.KB <= 16) return launch_fused(mode, a0, tiles, 1, st);
+    if (g.tile_w == 32) return launch_fused32(mode, a0, 2 * tiles, 1, st);
     FusedArgs a = a0;
     a.sk_tiles = tiles;
     const int64_t units = (int64_t)tiles * ((a.B + 31) / 32);
-    return launch_fused64k(MODE_SCORE, a, (int)std::min<int64_t>(std::min(cu_count(), 511), units), 1, st);
+    return launch_fused64k(mode, a, (int)std::min<int64_t>(std::min(cu_count(), 511), units), 1, st);
 }
 
 // Arguments of candidate range r (geometry: ranges of g.range_n candidates): local candidate 0 of the launch is
@@ -341,7 +341,7 @@ int lse_pass(const Geometry &g, const FusedArgs &base, char *ws, float *row_lse,
         hipError_t e;
         {
             ScopedTimer tm("fused_tile_stats", st);
-            e = g.KB <= 16 ? launch_fused(MODE_STATS, s, tiles_r, 1, st) : launch_fused32(MODE_STATS, s, 2 * tiles_r, 1, st);
+            e = launch_score_sweep(g, s, tiles_r, st, MODE_STATS);      // (slot sizes above 256: four 16-candidate blocks per tile)
             if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<stats>");
         }
         ScopedTimer tm("kl_row_lse", st);

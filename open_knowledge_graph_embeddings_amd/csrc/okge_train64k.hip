@@ -62,8 +62,11 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
     constexpr int D16 = 16 * KB, KH = 16 * KBW;                 // padded slot size, columns of one half
     constexpr int NQ = 4 * KB, QG = 16, NQIT = NQ / QG;         // float4 per row; staging: 16 column groups per row
     static_assert(KB % 8 == 0, "the column split needs whole quads of 16-column blocks per wave");
-    static_assert(MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL || MODE == MODE_SCORE, "training kernel, or the score sweep");
-    constexpr bool TRAIN = MODE != MODE_SCORE;           // MODE_SCORE: the same sweep stops after the score blocks and writes X
+    static_assert(MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL || MODE == MODE_SCORE || MODE == MODE_STATS,
+                  "training kernel, or the score / statistics sweep");
+    // MODE_SCORE / MODE_STATS: the same sweep stops after the score blocks and writes X, or per (16-candidate block, row) the
+    // (max, sum-exp) pairs of the KL loss' log-softmax (kl_row_lse_kernel merges them)
+    constexpr bool TRAIN = MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL;
     const int d = a.d;
     float *Qb = reinterpret_cast<float *>(smem);                              // [2][32][LDK]  (end: [64][LDK] gradient stage)
     v4f *xs = reinterpret_cast<v4f *>(Qb + 2 * BCK * LDK);                    // [8 waves][2 row groups][64 lanes]
@@ -281,6 +284,26 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
             }
             continue;
         }
+        if (MODE == MODE_STATS) {
+            // per row: max and sum-exp over this wave's 16 candidates -> stats[(4 tile + blk)][row]; partner ks takes row group ks
+            const v4f x = ks == 0 ? x0 : x1;
+            const bool nvalid = n0 + 16 * blk + c < a.N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float m = nvalid ? x[i] : -INFINITY;
+                m = row16_max(m);
+                float se = nvalid ? __expf(x[i] - m) : 0.f;
+                se = row16_sum(se);
+                const int b = b0 + 16 * ks + 4 * s + i;
+                if (c == 0 && b < b_end)
+                    reinterpret_cast<float2 *>(a.stats)[(size_t)(4 * tile + blk) * a.Bpad + b] = make_float2(m, se);
+            }
+            if (b0 + BCK < b_end) {
+                park_chunk(Qn);
+                if (b0 + 2 * BCK < b_end) fetch_chunk(b0 + 2 * BCK);
+            }
+            continue;
+        }
 
         // B operands (query rows) of the dC product's first step: requested now, consumed after the epilogue
         const float *qb = Qc + (4 * s) * LDK + KH * ks + 4 * c;
@@ -467,8 +490,10 @@ hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y,
     const dim3 grid(grid_x, grid_y);
     if (a.KB == 16 && (mode == MODE_TRAIN_BCE || mode == MODE_TRAIN_KL))      // experiment (OKGE_TILE64K_D256=1): d <= 256 on this layout
         return mode == MODE_TRAIN_KL ? launch64k_t<16, MODE_TRAIN_KL>(a, grid, st) : launch64k_t<16, MODE_TRAIN_BCE>(a, grid, st);
-    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL && mode != MODE_SCORE) || a.KB != 32) return hipErrorInvalidValue;
+    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL && mode != MODE_SCORE && mode != MODE_STATS) || a.KB != 32)
+        return hipErrorInvalidValue;
     if (mode == MODE_SCORE) return launch64k_t<32, MODE_SCORE>(a, grid, st);
+    if (mode == MODE_STATS) return launch64k_t<32, MODE_STATS>(a, grid, st);
     return mode == MODE_TRAIN_KL ? launch64k_t<32, MODE_TRAIN_KL>(a, grid, st) : launch64k_t<32, MODE_TRAIN_BCE>(a, grid, st);
 }
 
