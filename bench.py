@@ -254,6 +254,10 @@ def main():
         # exchange 1 as an all-gather of the rows each rank owns: the plan is host work on ids the host already has
         from open_knowledge_graph_embeddings_amd.sharded import make_exchange_plan
         plans = [make_exchange_plan(hb["po_obj"], hb["sp_subj"], w.n_ent, world, dev) for hb in host_batches]
+        # ... and so are the row segments of the prefix backward (relation / entity gradients without float atomics; None for
+        # batches under 1024 rows, where the atomics are cheaper than the second launch)
+        from open_knowledge_graph_embeddings_amd.sharded import make_row_segments
+        segs = [make_row_segments(hb["po_rel"], hb["po_obj"], hb["sp_subj"], hb["sp_rel"], dev) for hb in host_batches]
         w_run = wg
     else:
         host_batches = [synthetic.make_batch(w, seed=1234 + i) for i in range(N_BATCHES)]
@@ -274,7 +278,7 @@ def main():
     # host keeps ahead of a 0.15 ms step anyway -- so the default is plain launches.
     run = lambda i: step.step(batches[i % N_BATCHES])                       # noqa: E731
     if sharded:
-        run = lambda i: step.step(batches[i % N_BATCHES], plan=plans[i % N_BATCHES])   # noqa: E731
+        run = lambda i: step.step(batches[i % N_BATCHES], plan=plans[i % N_BATCHES], rel_segments=segs[i % N_BATCHES])   # noqa: E731
     if not sharded and os.environ.get("OKGE_BENCH_GRAPH", "0") == "1":
         from open_knowledge_graph_embeddings_amd.train_step import GraphedTrainStep
         g0 = GraphedTrainStep(step, batches[0], pos_capacity=batches[0].nnz)

@@ -436,7 +436,10 @@ class ReplicaStep:
             normalizer = float(batch.B) * float(batch.n_candidates)
         return self.inner.forward_backward(batch, normalizer * self.world)
 
-    def exchange(self, batch, loss=None):
+    def exchange(self, batch, loss=None, ready=None):
+        """`ready`: an event recorded on the current stream BEFORE the forward / backward was issued (step() does that): the
+        side stream's mask work needs the batch's ids, not the backward, and waits for that event only; without it the side
+        stream joins behind everything issued so far (correct, no overlap)."""
         if self.world == 1:
             return
         if not self.sparse_idx:
@@ -445,9 +448,15 @@ class ReplicaStep:
         else:
             if self.side is not None:
                 main = torch.cuda.current_stream(self.dev)
+                if ready is not None:
+                    self.side.wait_event(ready)
+                else:
+                    self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):                               # beside the backward still running on `main`
                     union = self._union_rows(batch)
                 main.wait_stream(self.side)
+                for _, rows in union:                   # allocated on the side stream, read by kernels of the current one:
+                    rows.record_stream(main)            # the allocator must not hand the block out again before those ran
             else:
                 union = self._union_rows(batch)
             need = self._small + sum(r.numel() * self.grads[i].shape[1] for i, r in union)
@@ -471,7 +480,8 @@ class ReplicaStep:
             dist.all_reduce(loss, group=self.group)
 
     def step(self, batch, normalizer=None):
+        ready = torch.cuda.current_stream(self.dev).record_event() if (self.side is not None and self.world > 1) else None
         loss = self.forward_backward(batch, normalizer)
-        self.exchange(batch, loss)
+        self.exchange(batch, loss, ready)
         self.inner.optimizer_step()
         return loss
