@@ -60,3 +60,68 @@ def test_integration_doc_maps_every_entry_point():
     declared = sorted(set(re.findall(r"\b(okge_[a-z0-9_]+)\s*\(", header)))
     assert len(declared) >= 30
     assert [f for f in declared if f not in doc] == []
+
+
+def test_streamk_run_and_slab_arithmetic():
+    """The stream-K launch of fused_tile64k_kernel (okge_train64k.hip) and dc_reduce_streamk_kernel (okge_misc.hip) agree on
+    who writes which partial-gradient slab by ARITHMETIC alone (no plan travels): this mirrors both sides' integer formulas and
+    checks, for many (tiles, chunks per tile, workgroups), that the runs tile the units exactly once, that a workgroup writes
+    at most two slabs (2p for its first segment, 2p + 1 for its last), and that the slabs the reduce kernel lists for a tile
+    are exactly the ones written for it, in run order; tiles covered by one whole segment list nothing."""
+    import random
+
+    def kernel_segments(T, J, P):
+        """per workgroup p: [(tile, j0, j1, slab or None)] as the tile kernel's segment loop derives them"""
+        U = T * J
+        out = []
+        for p in range(P):
+            u, u_end = U * p // P, U * (p + 1) // P
+            u_first, segs = u, []
+            while u < u_end:
+                tile = u // J
+                j0, j1 = u - tile * J, min(J, u_end - tile * J)
+                whole = j0 == 0 and j1 == J
+                segs.append((tile, j0, j1, None if whole else 2 * p + (0 if u == u_first else 1)))
+                u = tile * J + j1
+            out.append(segs)
+        return out
+
+    def reduce_slots(T, J, P, t):
+        """the slab list dc_reduce_streamk_kernel builds for tile t ([] = the tile kernel stored the tile itself)"""
+        U, lo, hi = T * J, t * J, t * J + J
+        p = lo * P // U
+        while p > 0 and U * p // P > lo:
+            p -= 1
+        while U * (p + 1) // P <= lo:
+            p += 1
+        slots = []
+        while p < P and U * p // P < hi:
+            ub, ue = U * p // P, U * (p + 1) // P
+            j0, j1 = max(ub, lo) - lo, min(ue, hi) - lo
+            if j1 > j0:
+                if j0 == 0 and j1 == J:
+                    return []
+                slots.append(2 * p + (0 if ub >= lo else 1))
+            p += 1
+        return slots
+
+    rng = random.Random(5)
+    cases = [(157, 16, 256), (1, 1, 1), (1, 16, 256), (3, 5, 7), (300, 16, 256), (33, 8, 256), (2, 128, 256), (1000, 2, 256)]
+    cases += [(rng.randint(1, 400), rng.randint(1, 40), rng.randint(1, 300)) for _ in range(200)]
+    for T, J, P in cases:
+        P = min(P, T * J)                                    # the launcher never starts more workgroups than units
+        segs = kernel_segments(T, J, P)
+        cover = [[0] * J for _ in range(T)]
+        written = {t: [] for t in range(T)}
+        for p, lst in enumerate(segs):
+            assert sum(1 for s in lst if s[3] is not None) <= 2, (T, J, P, p)
+            assert len({s[3] for s in lst if s[3] is not None}) == sum(1 for s in lst if s[3] is not None)
+            for tile, j0, j1, slab in lst:
+                for j in range(j0, j1):
+                    cover[tile][j] += 1
+                if slab is not None:
+                    written[tile].append(slab)
+        assert all(c == 1 for row in cover for c in row), (T, J, P)
+        for t in range(T):
+            assert reduce_slots(T, J, P, t) == written[t], (T, J, P, t)
+            assert len(written[t]) != 1, (T, J, P, t)       # a partial tile has at least two partial segments
