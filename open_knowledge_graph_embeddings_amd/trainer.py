@@ -149,12 +149,14 @@ class AddLossModule(nn.Module):
         if self.training_outputs or not m.training:
             all_outputs = torch.empty((B, (n + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :n]
         smoothing = self.bce_label_smoothing if kind == "bce" else 0.0
+        if getattr(m, "encode_in_torch", False):
+            return self._variant_result(m, batch, kind, smoothing, want_grad, all_outputs, epoch,
+                                        all_entities=not use_batch_shared_entities and not m.training,
+                                        per_direction=batch_shared_entities is None)
+        # (read AFTER the variant dispatch: the variants fill the hook while they encode, trainer.py:97-98)
         hook_loss = m.after_batch_loss_hook(epoch) if hasattr(m, "after_batch_loss_hook") else None
         if token_model:
             return self._token_result(m, batch, kind, smoothing, want_grad, all_outputs, hook_loss)
-        if getattr(m, "encode_in_torch", False):
-            return self._variant_result(m, batch, kind, smoothing, want_grad, all_outputs, epoch,
-                                        batch_shared_entities is None or (not use_batch_shared_entities and not m.training))
         if m.training:
             m.dropout_step += 1
         batch.drop_cand = m.dropout_spec(H.STREAM_CAND)
@@ -185,39 +187,67 @@ class AddLossModule(nn.Module):
             result = loss.to(torch.float32).reshape(())
         return result, hook_loss, all_outputs
 
-    def _variant_result(self, m, batch, kind, smoothing, want_grad, all_outputs, epoch, all_entities):
+    def _variant_result(self, m, batch, kind, smoothing, want_grad, all_outputs, epoch, all_entities, per_direction):
         """lookup embedder with batch_norm / projection / normalize / l2_reg on (model.py:463-479): torch encodes in the
-        reference's call order -- candidates once (trainer.py:75-82), then (rel, obj) of the po rows, (subj, rel) of the sp
-        rows (model.py:52-74) -- and the HIP scorer / loss / backward works on the encoded rows"""
+        reference's call order and the HIP scorer / loss / backward works on the encoded rows.
+        With a shared id list (trainer.py:75-84): candidates once -- get_all_obj() in eval without batch sharing, else
+        precompute_batch_shared_inputs -- then (rel, obj) of the po rows, (subj, rel) of the sp rows (model.py:52-74).
+        With batch_shared_entities=None (trainer.py:86-87) each prefix scorer encodes its OWN candidate block:
+        po_prefix_score get_all_subj() first, sp_prefix_score get_all_obj() last (model.py:60-61, :71-72) -- two blocks
+        that differ under project_entity (subj_ vs obj_projection), and two batch-norm / l2-hook passes either way; the
+        two directions then run as two fused calls whose losses add (reduction='sum' is a plain sum over rows)."""
         dev = m.entity_embedding.weight.device
         n_po, n_sp, n_c = batch.n_po, batch.n_sp, batch.n_candidates
-        with torch.set_grad_enabled(want_grad):
-            if all_entities:
-                cand = m.get_all_obj()
-            elif batch.cand_ids is not None:
-                cand = m.precompute_batch_shared_inputs(batch.cand_ids)
-            else:
-                cand = m.precompute_batch_shared_inputs(torch.arange(batch.cand_first, batch.cand_first + n_c, dtype=torch.int32, device=dev))
-            parts_e, parts_r = [cand.reshape(n_c, -1)], []
-            if n_po:
-                parts_r.append(m.encode_rel(batch.po_rel).reshape(n_po, -1))
-                parts_e.append(m.encode_obj(batch.po_obj).reshape(n_po, -1))
-            if n_sp:
-                parts_e.append(m.encode_subj(batch.sp_subj).reshape(n_sp, -1))
-                parts_r.append(m.encode_rel(batch.sp_rel).reshape(n_sp, -1))
-            EV, RV = torch.cat(parts_e), torch.cat(parts_r)
-        hook_loss = m.after_batch_loss_hook(epoch)
         ar = lambda a, b: torch.arange(a, b, dtype=torch.int32, device=dev)        # noqa: E731
-        vb = H.PrefixBatch(po_rel=ar(0, n_po) if n_po else None, po_obj=ar(n_c, n_c + n_po) if n_po else None,
-                           sp_subj=ar(n_c + n_po, n_c + n_po + n_sp) if n_sp else None, sp_rel=ar(n_po, n_po + n_sp) if n_sp else None,
-                           pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=n_c)
+        calls = []                                                                  # (EV, RV, virtual batch, output rows)
+        with torch.set_grad_enabled(want_grad):
+            if per_direction:
+                in_po = batch.pos_row < n_po
+                if n_po:
+                    cand = m.get_all_subj().reshape(n_c, -1)
+                    rel = m.encode_rel(batch.po_rel).reshape(n_po, -1)
+                    obj = m.encode_obj(batch.po_obj).reshape(n_po, -1)
+                    vb = H.PrefixBatch(po_rel=ar(0, n_po), po_obj=ar(n_c, n_c + n_po), pos_row=batch.pos_row[in_po],
+                                       pos_col=batch.pos_col[in_po], cand_first=0, n_cand=n_c)
+                    calls.append((torch.cat([cand, obj]), rel, vb, slice(0, n_po)))
+                if n_sp:
+                    subj = m.encode_subj(batch.sp_subj).reshape(n_sp, -1)
+                    rel = m.encode_rel(batch.sp_rel).reshape(n_sp, -1)
+                    cand = m.get_all_obj().reshape(n_c, -1)
+                    vb = H.PrefixBatch(sp_subj=ar(n_c, n_c + n_sp), sp_rel=ar(0, n_sp), pos_row=batch.pos_row[~in_po] - n_po,
+                                       pos_col=batch.pos_col[~in_po], cand_first=0, n_cand=n_c)
+                    calls.append((torch.cat([cand, subj]), rel, vb, slice(n_po, n_po + n_sp)))
+            else:
+                if all_entities:
+                    cand = m.get_all_obj()
+                elif batch.cand_ids is not None:
+                    cand = m.precompute_batch_shared_inputs(batch.cand_ids)
+                else:
+                    cand = m.precompute_batch_shared_inputs(ar(batch.cand_first, batch.cand_first + n_c))
+                parts_e, parts_r = [cand.reshape(n_c, -1)], []
+                if n_po:
+                    parts_r.append(m.encode_rel(batch.po_rel).reshape(n_po, -1))
+                    parts_e.append(m.encode_obj(batch.po_obj).reshape(n_po, -1))
+                if n_sp:
+                    parts_e.append(m.encode_subj(batch.sp_subj).reshape(n_sp, -1))
+                    parts_r.append(m.encode_rel(batch.sp_rel).reshape(n_sp, -1))
+                vb = H.PrefixBatch(po_rel=ar(0, n_po) if n_po else None, po_obj=ar(n_c, n_c + n_po) if n_po else None,
+                                   sp_subj=ar(n_c + n_po, n_c + n_po + n_sp) if n_sp else None,
+                                   sp_rel=ar(n_po, n_po + n_sp) if n_sp else None,
+                                   pos_row=batch.pos_row, pos_col=batch.pos_col, cand_first=0, n_cand=n_c)
+                calls.append((torch.cat(parts_e), torch.cat(parts_r), vb, slice(0, n_po + n_sp)))
+        hook_loss = m.after_batch_loss_hook(epoch)
         eng = m.engine()
-        if want_grad:
-            result = _VirtualTablesLossFn.apply(EV, RV, eng, m.scorer_name, vb, kind, smoothing, all_outputs)
-        else:
-            loss = eng.forward_backward(EV.detach().contiguous(), RV.detach().contiguous(), m.scorer_name, vb, None, None, loss=kind,
-                                        label_smoothing=smoothing, normalizer=1.0, scores=all_outputs, loss_only=True)
-            result = loss.to(torch.float32).reshape(())
+        result = None
+        for EV, RV, vb, rows in calls:
+            out = all_outputs[rows] if all_outputs is not None else None
+            if want_grad:
+                part = _VirtualTablesLossFn.apply(EV, RV, eng, m.scorer_name, vb, kind, smoothing, out)
+            else:
+                part = eng.forward_backward(EV.detach().contiguous(), RV.detach().contiguous(), m.scorer_name, vb, None, None,
+                                            loss=kind, label_smoothing=smoothing, normalizer=1.0, scores=out,
+                                            loss_only=True).to(torch.float32).reshape(())
+            result = part if result is None else result + part
         return result, hook_loss, all_outputs
 
     def _token_result(self, m, batch, kind, smoothing, want_grad, all_outputs, hook_loss):

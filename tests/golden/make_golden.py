@@ -958,15 +958,21 @@ def g14():
 # ----------------------------------------------------------------------------------------------
 # G12: embedder variants of the lookup models (batch-norm, entity projection, normalisation, l2_reg hook)
 # ----------------------------------------------------------------------------------------------
-def g12():
+def g12(only_cases=()):
     """LookupComplexRelationModel with the _encode variants of model.py:463-479 switched on (dropout 0: torch's CPU
     Bernoulli stream is not reproducible elsewhere): AddLossModule forward, Trainer's backward_loss = (loss + hook) /
     normalizer (trainer.py:217-222), gradients of EVERY parameter, batch-norm running statistics after the step, and an
     eval-mode forward afterwards."""
     cases = {"bn": dict(batch_norm=True), "proj": dict(project_entity=True), "norm": dict(normalize="norm"),
-             "l2": dict(l2_reg=0.01), "all": dict(batch_norm=True, project_entity=True, normalize="norm", l2_reg=0.01)}
+             "l2": dict(l2_reg=0.01), "all": dict(batch_norm=True, project_entity=True, normalize="norm", l2_reg=0.01),
+             # batch_shared_entities=None (trainer.py:86-87): each prefix scorer encodes its own candidate block
+             # (get_all_subj for the po rows, get_all_obj for the sp rows, model.py:60-61 / :71-72)
+             "all_noshare": dict(batch_norm=True, project_entity=True, normalize="norm", l2_reg=0.01)}
     n_ent, n_rel, d, b = 60, 8, 16, 6
     for name, kw in cases.items():
+        if only_cases and name not in only_cases:
+            continue
+        no_shared = name.endswith("_noshare")
         seed = 120 + len(name)
         rng = np.random.default_rng(seed)
         torch.manual_seed(seed)
@@ -982,7 +988,7 @@ def g12():
         sp_subj, sp_rel = rand_ids(rng, 2, n_ent, b), rand_ids(rng, 2, n_rel, b)
         y = dense_labels(rng, 2 * b, N)
         loss, hook, outputs = mod(inputs=[(po_rel, po_obj), (sp_subj, sp_rel)], labels=torch.from_numpy(y.copy()),
-                                  use_batch_shared_entities=False, batch_shared_entities=cand, epoch=1,
+                                  use_batch_shared_entities=False, batch_shared_entities=None if no_shared else cand, epoch=1,
                                   input_style_triple_or_prefix="right_and_left_prefix")
         normalizer = float(2 * b * N)
         backward_loss = loss.sum()
@@ -992,7 +998,7 @@ def g12():
         out = dict(case=np.str_(name), kw_keys=np.asarray(sorted(kw)), po_rel=npy(po_rel), po_obj=npy(po_obj), sp_subj=npy(sp_subj),
                    sp_rel=npy(sp_rel), cand=npy(cand), labels=y, loss=np.float64(loss.item()),
                    hook=np.float64(hook.item() if hook is not None else 0.0), has_hook=np.bool_(hook is not None),
-                   outputs=npy(outputs), normalizer=np.float64(normalizer),
+                   outputs=npy(outputs), normalizer=np.float64(normalizer), no_shared=np.bool_(no_shared),
                    batch_norm=np.bool_(kw.get("batch_norm", False)), project_entity=np.bool_(kw.get("project_entity", False)),
                    normalize=np.str_(kw.get("normalize", "")), l2_reg=np.float64(kw.get("l2_reg", 0)))
         for k, v in state0.items():
@@ -1056,6 +1062,8 @@ def g8():
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
     for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
-        if not only or fn.__name__ in only:
+        if fn is g12 and any(a.startswith("g12:") for a in only):    # `make_golden.py g12:all_noshare`: one case of the family
+            fn(tuple(a[4:] for a in only if a.startswith("g12:")))
+        elif not only or fn.__name__ in only:
             fn()
     print("torch", torch.__version__, "numpy", np.__version__)

@@ -47,7 +47,10 @@ def test_variant_forward_backward_matches_reference(okge_lib, name):
     mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
     inputs = [(t(z["po_rel"]), t(z["po_obj"])), (t(z["sp_subj"]), t(z["sp_rel"]))]
-    loss, hook, outs = mod(inputs=inputs, labels=t(z["labels"]), use_batch_shared_entities=False, batch_shared_entities=t(z["cand"]),
+    # *_noshare: batch_shared_entities=None -- every prefix scorer encodes its own candidate block (trainer.py:86-87)
+    no_shared = "no_shared" in z.files and bool(z["no_shared"])
+    shared = None if no_shared else t(z["cand"])
+    loss, hook, outs = mod(inputs=inputs, labels=t(z["labels"]), use_batch_shared_entities=False, batch_shared_entities=shared,
                            epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
     np.testing.assert_allclose(outs.cpu().numpy(), z["outputs"], rtol=0, atol=1e-4)
     assert abs(float(loss.detach()) - float(z["loss"])) <= 3e-5 * abs(float(z["loss"]))
@@ -67,13 +70,13 @@ def test_variant_forward_backward_matches_reference(okge_lib, name):
     m.eval()
     with torch.no_grad():
         ev = torch.cat([m.po_prefix_score(*inputs[0]), m.sp_prefix_score(*inputs[1])], 0)
-        l2, h2, o2 = mod(inputs=inputs, labels=t(z["labels"]), use_batch_shared_entities=False, batch_shared_entities=t(z["cand"]),
+        l2, h2, o2 = mod(inputs=inputs, labels=t(z["labels"]), use_batch_shared_entities=False, batch_shared_entities=shared,
                          epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
     np.testing.assert_allclose(ev.cpu().numpy(), z["eval_outputs"], rtol=0, atol=1e-4)
     # AddLossModule in eval mode scores BOTH directions against get_all_obj() (trainer.py:77-78); with an entity
     # projection the po rows therefore differ from po_prefix_score's (get_all_subj): compare what must agree
     n_po = z["po_rel"].shape[0]
     np.testing.assert_allclose(o2[n_po:].cpu().numpy(), z["eval_outputs"][n_po:], rtol=0, atol=1e-4)
-    if not bool(z["project_entity"]):
+    if no_shared or not bool(z["project_entity"]):
         np.testing.assert_allclose(o2[:n_po].cpu().numpy(), z["eval_outputs"][:n_po], rtol=0, atol=1e-4)
     assert h2 is None and torch.isfinite(l2)
