@@ -143,6 +143,9 @@ struct Geometry {
     int    B, N, d, Bpad, D16, KB, LDK, ldq, ldg, tiles, b_split, b_per_block, nsplit;
     int    tile_w, ktiles;      // fused train kernel: tile width (32 or 64 candidates) and tile count
     int    sk_wgs, sk_chunks;   // > 0: the train tile kernel is launched stream-K shaped over sk_wgs workgroups (okge_train64k.hip)
+    // > 0: the LAST `tail_tiles` candidate tiles of the call (what is left over after whole rounds of one workgroup per CU)
+    // are launched apart with the batch rows split over tail_split workgroups each, so the closing round is short
+    int    tail_tiles, tail_split, tail_b_per_block;
     bool   dq8;
     // training sweeps the candidates in RANGES of range_n (a multiple of 64) so that the one (B, N)-shaped
     // intermediate, G^T, and everything sized like it (masked rows Cm, KL statistics) is O(B x range_n):
@@ -173,6 +176,25 @@ int cu_count()
     return cus[dev];
 }
 
+// Tail split of a launch of `tiles` equal tiles, one workgroup per CU (slot sizes up to 256): the `tail` tiles left over after
+// whole rounds would cost a whole round's time; launched apart with the rows split `split` ways they cost 1 / split of it.
+// Worth it when the rows per workgroup drop by at least two 64-row blocks.  (cfg4 shard: 4883 tiles = 19 rounds + 19 tiles.)
+struct TailSplit { int tiles, split, b_per_block; };
+TailSplit tail_split(int tiles, int Bpad, int slots)
+{
+    TailSplit t = {0, 0, Bpad};
+    const int bblks = Bpad / BC, tail = tiles % slots;
+    if (tiles <= slots || tail == 0 || env_int("OKGE_TAIL_SPLIT", 1) == 0) return t;
+    const int c = std::min(slots / tail, bblks);
+    if (c < 2) return t;
+    const int per = (bblks + c - 1) / c;
+    if (bblks - per < 2) return t;
+    t.tiles = tail;
+    t.b_per_block = per * BC;
+    t.split = (Bpad + t.b_per_block - 1) / t.b_per_block;
+    return t;
+}
+
 bool make_geometry(int B, int N, int d, Geometry &g)
 {
     if (B <= 0 || N <= 0 || d <= 0) return false;
@@ -194,7 +216,13 @@ bool make_geometry(int B, int N, int d, Geometry &g)
         rt = std::max<int64_t>(1, std::min<int64_t>(rt, g.tiles));
         g.range_tiles = (int)rt;
         g.n_ranges = (g.tiles + g.range_tiles - 1) / g.range_tiles;
-        g.range_tiles = (g.tiles + g.n_ranges - 1) / g.n_ranges;                  // even out the ranges
+        if (g.n_ranges > 1 && g.KB <= 16 && rt >= 256) {
+            // slot sizes up to 256 run one workgroup per CU and tile: ranges of whole rounds (a multiple of 256 tiles), so
+            // that only the LAST range ends in a partial round -- the one the tail split below shortens
+            g.range_tiles = (int)(rt / 256 * 256);
+        } else {
+            g.range_tiles = (g.tiles + g.n_ranges - 1) / g.n_ranges;              // even out the ranges
+        }
         g.n_ranges = (g.tiles + g.range_tiles - 1) / g.range_tiles;
         g.range_n = g.range_tiles * NT;
         g.range_ktiles = 2 * g.range_tiles;
@@ -235,6 +263,16 @@ bool make_geometry(int B, int N, int d, Geometry &g)
         g.b_split = 1;
         g.b_per_block = g.Bpad;
     }
+    // tail split (slot sizes up to 256, more tiles than CUs): equal tiles in rounds of one per CU leave a closing round with
+    // `tail` < 256 workgroups that still takes a whole round's time (cfg4 shard: 4883 tiles = 19 rounds + 19 tiles -> 20 rounds,
+    // 4.6 % of the kernel idle).  The tail tiles are launched apart with the rows split floor(256 / tail) ways; their partial
+    // candidate gradients go through the batch-split slabs + dc_reduce.  Worth it when the rows per workgroup drop by >= 2 blocks.
+    g.tail_tiles = g.tail_split = 0;
+    g.tail_b_per_block = g.Bpad;
+    if (g.KB <= 16 && g.tile_w == 64 && g.b_split == 1) {
+        const TailSplit ts = tail_split(g.tiles - (g.n_ranges - 1) * g.range_tiles, g.Bpad, slots);
+        if (ts.split > 1) { g.tail_tiles = ts.tiles; g.tail_split = ts.split; g.tail_b_per_block = ts.b_per_block; }
+    }
     // dQ kernel: (batch block, candidate range) workgroups: 8-wave workgroups, one per CU (d <= 256), else 4-wave, two per CU
     // (slot sizes above 256: dq8k_kernel, 32-candidate chunks double-buffered; OKGE_DQ8K=0 selects dq_kernel<32>)
     g.dq8 = (g.KB <= 16 && env_int("OKGE_DQ8", 1) != 0) || (g.KB == 32 && env_int("OKGE_DQ8K", 1) != 0);
@@ -255,12 +293,13 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     g.off_run = off;   off += align_up((size_t)g.Bpad * 2 * sizeof(float), 256);
     g.lse_bytes = off;
     // [training part]
-    g.off_loss = off;  off += align_up((size_t)std::max(2 * g.tiles * g.b_split, g.sk_wgs) * sizeof(double), 256);
+    g.off_loss = off;  off += align_up((size_t)std::max(2 * g.tiles * g.b_split + g.tail_tiles * g.tail_split, g.sk_wgs) * sizeof(double), 256);
     g.off_GT = off;    off += align_up((size_t)g.Bpad * g.ldg * sizeof(float), 256);
     g.off_Cm = off;    off += align_up((size_t)g.range_tiles * NT * g.D16 * sizeof(float), 256);
     g.off_slab = off;  off += align_up((size_t)g.nsplit * g.Bpad * g.ldq * sizeof(float), 256);
     g.off_dcs = off;   off += g.sk_wgs > 0 ? align_up((size_t)2 * g.sk_wgs * NT * g.D16 * sizeof(float), 256)
-                                     : g.b_split > 1 ? align_up((size_t)g.b_split * g.tiles * NT * g.D16 * sizeof(float), 256) : 0;
+                                     : g.b_split > 1 ? align_up((size_t)g.b_split * g.tiles * NT * g.D16 * sizeof(float), 256)
+                                     : g.tail_split > 1 ? align_up((size_t)g.tail_split * g.tail_tiles * NT * g.D16 * sizeof(float), 256) : 0;
     g.total = off;
     return true;
 }
@@ -298,11 +337,39 @@ void fill_fused_common(FusedArgs &a, const Geometry &g, const okge_tables *t, co
 }
 
 
-// the score sweep (MODE_SCORE) of `tiles` 64-candidate tiles over all B rows: the 64 x 64 kernel up to slot size 256; above, the
-// register-tile kernel in a stream-K launch (rows are independent: no partial outputs to add up), or the 32 x 32 cut it replaced
+// Arguments of the tiles from `t0` on of a launch: every per-tile pointer and the candidate window move with them
+FusedArgs tile_window(const FusedArgs &base, const Geometry &g, int t0)
+{
+    FusedArgs a = base;
+    a.N = base.N - t0 * NT;
+    a.cand_first += t0 * NT;
+    if (a.cand_ids) a.cand_ids += t0 * NT;
+    a.cand_col0 += t0 * NT;
+    if (a.tile_ptr) a.tile_ptr += t0;
+    if (a.loss_partial) a.loss_partial += t0;
+    if (a.G) a.G += (size_t)t0 * (g.Bpad / BC) * (BC * NT);
+    if (a.Cm) a.Cm += (size_t)t0 * NT * g.D16;
+    if (a.X) a.X += (size_t)t0 * NT;
+    if (a.stats) a.stats += (size_t)t0 * g.Bpad * 2;
+    if (a.rk_slab) a.rk_slab += (size_t)t0 * a.rk_ngroups;
+    return a;
+}
+
+// the score sweep (MODE_SCORE / _STATS / _COUNT) of `tiles` 64-candidate tiles over all B rows: the 64 x 64 kernel up to slot size
+// 256 (rows are independent: the tail tiles simply run as (tile, row split) workgroups); above, the register-tile kernel in a
+// stream-K launch (no partial outputs to add up), or the 32 x 32 cut it replaced
 hipError_t launch_score_sweep(const Geometry &g, const FusedArgs &a0, int tiles, hipStream_t st, int mode = MODE_SCORE)
 {
-    if (g.KB <= 16) return launch_fused(mode, a0, tiles, 1, st);
+    if (g.KB <= 16) {
+        const TailSplit ts = a0.b_per_block >= g.Bpad ? tail_split(tiles, g.Bpad, 256) : TailSplit{0, 0, g.Bpad};
+        if (ts.split < 2) return launch_fused(mode, a0, tiles, 1, st);
+        FusedArgs am = a0;
+        am.N = (tiles - ts.tiles) * NT;
+        if (hipError_t e = launch_fused(mode, am, tiles - ts.tiles, 1, st); e != hipSuccess) return e;
+        FusedArgs at = tile_window(a0, g, tiles - ts.tiles);
+        at.b_per_block = ts.b_per_block;
+        return launch_fused(mode, at, ts.tiles, ts.split, st);
+    }
     if (g.tile_w == 32) return launch_fused32(mode, a0, 2 * tiles, 1, st);
     FusedArgs a = a0;
     a.sk_tiles = tiles;
@@ -466,7 +533,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     a.G = reinterpret_cast<float *>(ws + g.off_GT);
     a.Cm = reinterpret_cast<float *>(ws + g.off_Cm);
     a.dE = dE;
-    a.dC_slab = (g.b_split > 1 || g.sk_wgs > 0) ? reinterpret_cast<float *>(ws + g.off_dcs) : nullptr;
+    a.dC_slab = (g.b_split > 1 || g.sk_wgs > 0 || g.tail_split > 1) ? reinterpret_cast<float *>(ws + g.off_dcs) : nullptr;
     a.loss_partial = reinterpret_cast<double *>(ws + g.off_loss);
     a.loss_kind = loss_kind;
     a.inv_norm = (float)(1.0 / normalizer);
@@ -508,22 +575,45 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     q.nsplit = g.nsplit;
     q.waves8 = g.dq8 ? 1 : 0;
     const int mode = loss_kind == OKGE_LOSS_KL ? MODE_TRAIN_KL : MODE_TRAIN_BCE;
-    const int n_loss_partials = g.sk_wgs > 0 ? g.sk_wgs : g.ktiles * g.b_split;
+    // (tail split: the tail launch's partials of row split y > 0 follow the per-tile ones -- index y * tail + x from the tail's
+    //  first tile is contiguous with them)
+    const int n_loss_partials = g.sk_wgs > 0 ? g.sk_wgs : g.ktiles * g.b_split + g.tail_tiles * std::max(0, g.tail_split - 1);
     for (int r = 0; r < g.n_ranges; ++r) {
         int tiles_r;
         const FusedArgs ar = range_args(a, g, r, tiles_r);
+        const int tail_r = (r == g.n_ranges - 1 && g.tail_split > 1) ? g.tail_tiles : 0;     // tiles of this range launched apart
+        FusedArgs at = ar;
         {
             ScopedTimer tm("fused_tile_train", st);
             if (g.sk_wgs > 0) {                     // stream-K: a.sk_tiles tiles x sk_chunks chunks over sk_wgs workgroups
                 FusedArgs as = ar;
                 as.sk_tiles = tiles_r;
                 e = launch_fused64(mode, as, g.sk_wgs, 1, st);
+            } else if (tail_r > 0) {
+                const int main_r = tiles_r - tail_r;
+                e = hipSuccess;
+                if (main_r > 0) {
+                    FusedArgs am = ar;
+                    am.N = main_r * NT;
+                    e = launch_fused64(mode, am, main_r, 1, st);
+                }
+                if (e == hipSuccess) {
+                    at = tile_window(ar, g, main_r);
+                    at.b_per_block = g.tail_b_per_block;
+                    e = launch_fused64(mode, at, tail_r, g.tail_split, st);
+                }
             } else {
                 e = g.tile_w == 64 ? launch_fused64(mode, ar, tiles_r, g.b_split, st) : launch_fused32(mode, ar, 2 * tiles_r, g.b_split, st);
             }
             if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
         }
         if (loss_only) continue;
+        if (tail_r > 0) {
+            ScopedTimer tm("dc_reduce", st);
+            e = launch_dc_reduce(a.dC_slab, g.tail_split, tail_r * NT, g.D16, at.N, g.d, at.cand_ids, at.cand_first, a.cand_exclusive,
+                                 a.grads_zero, dE, a.n_table_rows, a.id_err, st);
+            if (e != hipSuccess) return fail_hip(e, "dc_reduce");
+        }
         if (g.sk_wgs > 0) {
             ScopedTimer tm("dc_reduce", st);
             e = launch_dc_reduce_streamk(a.dC_slab, tiles_r, g.sk_chunks, g.sk_wgs, g.D16, ar.N, g.d, cand->ids, cand->first_id,
@@ -1148,7 +1238,7 @@ static int eval_issue(int phases, const EvalCall &c, hipStream_t st)
     }
     if (phases & 2) {
         ScopedTimer tm("fused_tile_count", st);
-        e = launch_fused(MODE_COUNT, c.sweep, c.g.tiles, 1, st);
+        e = c.g.KB <= 16 ? launch_score_sweep(c.g, c.sweep, c.g.tiles, st, MODE_COUNT) : launch_fused(MODE_COUNT, c.sweep, c.g.tiles, 1, st);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<count>");
     }
     if (phases & 4) {

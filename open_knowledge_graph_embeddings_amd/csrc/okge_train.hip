@@ -665,11 +665,15 @@ __global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
 // barrier per chunk, no staging phase --, the two waves of a SIMD take turns (group ks = 0 parks before its MFMAs, group
 // ks = 1 after), and the candidate range of a workgroup is twice as long (32 splits: half the slabs).  Wave (wq = w & 3,
 // ks = w >> 2): batch rows 16 wq .., output columns 256 ks ..; contraction rows of slot s: candidates 8 s + t, t < 8.
+// KB = 16 (slot sizes 209 .. 256, where two 64-candidate pairs do not fit the LDS and dq8_kernel runs its single-pair loop):
+// the same loop on 128-column halves.
+template <int KB>
 __global__ __launch_bounds__(512, 2) void dq8k_kernel(const DqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KB = 32, LDK = lds_ld(16 * KB), NTHR = 512, NC = 32;            // NC candidates per chunk
-    constexpr int KBW = KB / 2, KQ = KBW / 4;
+    constexpr int LDK = lds_ld(16 * KB), NC = 32;     // NC candidates per chunk
+    constexpr int KBW = KB / 2, KQ = KBW / 4, NV = KB / 4;   // NV float4 of a chunk row per staging thread
+    static_assert(KB % 8 == 0, "two column halves of whole float4 quads");
     constexpr int PAIR = NC * LDK + NC * LDGT;        // floats of one (candidate tile, G^T tile) pair
     float *Cs = reinterpret_cast<float *>(smem);      // [NC][LDK]
     float *Gt = Cs + NC * LDK;                        // [NC (n)][LDGT]
@@ -688,18 +692,18 @@ __global__ __launch_bounds__(512, 2) void dq8k_kernel(const DqArgs a)
     for (int kb = 0; kb < KBW; ++kb) acc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const int r16 = tid >> 4, q16 = tid & 15;         // staging: row r16 of the chunk, float4 columns q16 + 16 it
-    v4f gv, cv[8];
+    v4f gv, cv[NV];
     auto prefetch = [&](int ch) {
         gv = *reinterpret_cast<const v4f *>(a.G + ((size_t)(ch >> 1) * nJ + bblk) * 4096 + (ch & 1) * 2048 + (size_t)tid * 4);
         const float *cm = a.Cm + ((size_t)ch * NC + r16) * (16 * KB);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) cv[it] = *reinterpret_cast<const v4f *>(cm + 4 * (q16 + 16 * it));
+        for (int it = 0; it < NV; ++it) cv[it] = *reinterpret_cast<const v4f *>(cm + 4 * (q16 + 16 * it));
     };
     auto park = [&](int buf) {
         float *cs = Cs + buf * PAIR, *gt = Gt + buf * PAIR;
         *reinterpret_cast<v4f *>(gt + (tid >> 4) * LDGT + 4 * (tid & 15)) = gv;       // float4 number tid: candidate tid >> 4
 #pragma unroll
-        for (int it = 0; it < 8; ++it) *reinterpret_cast<v4f *>(cs + r16 * LDK + 4 * (q16 + 16 * it)) = cv[it];
+        for (int it = 0; it < NV; ++it) *reinterpret_cast<v4f *>(cs + r16 * LDK + 4 * (q16 + 16 * it)) = cv[it];
     };
     if (ch_lo < ch_hi) {
         prefetch(ch_lo);
@@ -804,6 +808,16 @@ static hipError_t launch_dq8_t(const DqArgs &a, int grid_x, size_t shmem, hipStr
     return hipGetLastError();
 }
 
+template <int KB>
+static hipError_t launch_dq8k_t(const DqArgs &a, int grid_x, hipStream_t st)
+{
+    const size_t sh = (size_t)2 * (32 * lds_ld(16 * KB) + 32 * LDGT) * sizeof(float);
+    static LdsOptIn lds_opt_in;
+    if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(dq8k_kernel<KB>), sh); e != hipSuccess) return e;
+    hipLaunchKernelGGL(dq8k_kernel<KB>, dim3(grid_x), dim3(512), sh, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st)
 {
     const size_t shmem = dq_shmem_bytes(a.LDK);
@@ -812,17 +826,15 @@ hipError_t launch_dq(const DqArgs &a, int grid_x, hipStream_t st)
             case 4:  return launch_dq8_t<4>(a, grid_x, shmem, st);
             case 8:  return launch_dq8_t<8>(a, grid_x, shmem, st);
             case 13: return launch_dq8_t<13>(a, grid_x, shmem, st);
-            case 16: return launch_dq8_t<16>(a, grid_x, shmem, st);
+            case 16: {
+                // 32-candidate chunks in two LDS pairs (dq8k_kernel<16>); OKGE_DQ8K16=0: the single-pair loop of dq8_kernel
+                static const bool k16 = [] { const char *e = getenv("OKGE_DQ8K16"); return !e || atoi(e) != 0; }();
+                return k16 ? launch_dq8k_t<16>(a, grid_x, st) : launch_dq8_t<16>(a, grid_x, shmem, st);
+            }
             default: break;
         }
     }
-    if (a.waves8 && a.KB == 32) {
-        const size_t sh = (size_t)2 * (32 * lds_ld(512) + 32 * LDGT) * sizeof(float);
-        static LdsOptIn lds_opt_in;
-        if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(dq8k_kernel), sh); e != hipSuccess) return e;
-        hipLaunchKernelGGL(dq8k_kernel, dim3(grid_x), dim3(512), sh, st, a);
-        return hipGetLastError();
-    }
+    if (a.waves8 && a.KB == 32) return launch_dq8k_t<32>(a, grid_x, st);
     switch (a.KB) {
         case 4:  return launch_dq_t<4>(a, grid_x, shmem, st);
         case 8:  return launch_dq_t<8>(a, grid_x, shmem, st);

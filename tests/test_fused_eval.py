@@ -296,3 +296,22 @@ def test_pipelined_evaluator_many_small_batches_lose_no_group(okge_lib):
         assert abs(res["mrr"].avg - ref["mrr"].avg) <= 1e-13
         seen.append(res["mrr"].avg)
     assert len(set(seen)) == 1                                   # per-chain rows summed in a fixed order: reproducible
+
+
+@pytest.mark.parametrize("d,scorer", [(32, "complex"), (200, "distmult"), (256, "complex")])
+def test_tail_split_sweeps(okge_lib, monkeypatch, d, scorer):
+    """more candidate tiles than CUs (275 = 256 + 19): the score sweep and the counting sweep launch the leftover tiles apart,
+    rows split across workgroups (okge_api.hip tail_split) -- rows are independent, so scores and ranks are BIT-EQUAL to the
+    plain launch (OKGE_TAIL_SPLIT=0), and both equal the materialising path and the oracle's rank rule"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    hp = H.HotPath("cuda:0")
+    rng = np.random.default_rng(77 + d)
+    E, R, batch, csr, N = _case(rng, 64 * 274 + 39, 30, d, 130, 126, scorer, max_groups=3, ties=False, many=70)
+    assert (N + 63) // 64 == 275 and batch.B == 256
+    got = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("OKGE_TAIL_SPLIT", split)
+        x = hp.score(_dev(E), _dev(R), scorer, batch).clone()
+        got[split] = (x, _check(hp, E, R, scorer, batch, csr, N).clone())
+    assert torch.equal(got["0"][0], got["1"][0])
+    assert torch.equal(got["0"][1], got["1"][1])

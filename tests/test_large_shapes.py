@@ -235,3 +235,58 @@ def test_candidate_ranges_match_single_range(okge_lib, monkeypatch):
         assert abs(one[0] - many[0]) <= 1e-6 * abs(one[0])
         np.testing.assert_allclose(many[1], one[1], rtol=0, atol=3e-6 * np.abs(one[1]).max())
         np.testing.assert_allclose(many[2], one[2], rtol=0, atol=3e-6 * np.abs(one[2]).max())
+
+
+@pytest.mark.parametrize("d,kind,ids", [(32, "bce", False), (200, "kl", False), (256, "bce", True), (200, "bce", True)])
+def test_tail_split_matches_plain_launch(okge_lib, monkeypatch, d, kind, ids):
+    """more candidate tiles than CUs: the tiles left over after whole rounds (275 tiles = 256 + 19 here) are launched apart
+    with the batch rows split across workgroups (okge_api.hip, make_geometry "tail split").  Same loss and gradients as the
+    plain launch (OKGE_TAIL_SPLIT=0), up to the order the tail's partial candidate gradients are added in; also with the
+    candidate ranges forced to 256 tiles, where the last range is ALL tail, and with an explicit candidate id list."""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    hp = H.HotPath("cuda:0")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(d + len(kind))
+    N, n_rel, b = 64 * 274 + 37, 30, 128                                   # 275 tiles, the last one ragged; B = 256 rows
+    n_ent = N + 2 + (500 if ids else 0)
+    E = torch.from_numpy((rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)).to(dev)
+    R = torch.from_numpy((rng.standard_normal((n_rel, d)) * 0.3).astype(np.float32)).to(dev)
+    coords = np.unique(np.stack([rng.integers(0, N, 4 * b), rng.integers(0, 2 * b, 4 * b)], 1), axis=0)
+    coords = np.concatenate([coords, [[N - 1, 0], [N - 1, 2 * b - 1], [64 * 256, 5]]]).astype(np.int64)   # positives inside the tail
+    coords = np.unique(coords, axis=0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)       # noqa: E731
+    cand_ids = t((2 + rng.permutation(n_ent - 2)[:N]).astype(np.int32)) if ids else None
+    out = {}
+    for split, mb in (("0", "1024"), ("1", "1024"), ("1", "16")):         # 16 MiB: ranges of 256 tiles at B = 256
+        monkeypatch.setenv("OKGE_TAIL_SPLIT", split)
+        monkeypatch.setenv("OKGE_GT_MBYTES", mb)
+        r2 = np.random.default_rng(4)
+        batch = H.PrefixBatch(po_rel=t(r2.integers(2, n_rel, b).astype(np.int32)), po_obj=t(r2.integers(2, n_ent, b).astype(np.int32)),
+                              sp_subj=t(r2.integers(2, n_ent, b).astype(np.int32)), sp_rel=t(r2.integers(2, n_rel, b).astype(np.int32)),
+                              pos_row=t(coords[:, 1].astype(np.int32)), pos_col=t(coords[:, 0].astype(np.int32)),
+                              cand_first=2, n_cand=N, cand_ids=cand_ids)
+        batch.drop_cand = H.DropoutSpec(0.3, 9, H.STREAM_CAND, 1)
+        batch.drop_po_ent = H.DropoutSpec(0.2, 9, H.STREAM_PO_ENT, 1)
+        hp._ws, hp._ws_bytes = None, 0
+        dE, dR = torch.full_like(E, 7.0), torch.zeros_like(R)              # grads_zero on a contiguous range: rows are STORED
+        if ids:
+            dE.zero_()
+        loss = hp.forward_backward(E, R, "complex", batch, dE, dR, loss=kind, grads_zero=not ids, label_smoothing=0.1 if kind == "bce" else 0.0)
+        torch.cuda.synchronize()
+        if not ids:
+            assert float(dE[:2].min()) == 7.0                              # rows in front of the candidates: untouched
+            dE[:2] = 0
+        out[(split, mb)] = (float(loss[0]), dE.cpu().numpy(), dR.cpu().numpy())
+    plain = out[("0", "1024")]
+    for key in (("1", "1024"), ("1", "16")):
+        got = out[key]
+        assert abs(plain[0] - got[0]) <= 1e-6 * abs(plain[0]), key
+        np.testing.assert_allclose(got[1], plain[1], rtol=0, atol=3e-6 * np.abs(plain[1]).max(), err_msg=str(key))
+        np.testing.assert_allclose(got[2], plain[2], rtol=0, atol=3e-6 * np.abs(plain[2]).max(), err_msg=str(key))
+    # candidate rows outside the tail come from the same tiles in both: bit-equal (rows that also receive a prefix gradient
+    # through float atomics aside)
+    if not ids:
+        r2 = np.random.default_rng(4)
+        _, po_obj, sp_subj, _ = (r2.integers(2, hi, b) for hi in (n_rel, n_ent, n_ent, n_rel))
+        rows = np.setdiff1d(np.arange(2, 2 + 64 * 256), np.concatenate([po_obj, sp_subj]))
+        np.testing.assert_array_equal(out[("1", "1024")][1][rows], plain[1][rows])
