@@ -667,7 +667,7 @@ __global__ __launch_bounds__(512, 2) void dq8_kernel(const DqArgs a)
 // ks = w >> 2): batch rows 16 wq .., output columns 256 ks ..; contraction rows of slot s: candidates 8 s + t, t < 8.
 // KB = 16 (slot sizes 209 .. 256, where two 64-candidate pairs do not fit the LDS and dq8_kernel runs its single-pair loop):
 // the same loop on 128-column halves.
-template <int KB>
+template <int KB, bool DEEP>
 __global__ __launch_bounds__(512, 2) void dq8k_kernel(const DqArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -687,44 +687,62 @@ __global__ __launch_bounds__(512, 2) void dq8k_kernel(const DqArgs a)
     const int ch_lo = (int)((int64_t)split * nchunks / a.nsplit);
     const int ch_hi = (int)((int64_t)(split + 1) * nchunks / a.nsplit);
 
-    v4f acc[KBW];                                     // dQ[b = b0 + 16wq + 4s + i][k = 256 ks + grad_col(kbi, c)]
+    v4f acc[KBW];                                     // dQ[b = b0 + 16wq + 4s + i][k = 16 KBW ks + grad_col(kbi, c)]
 #pragma unroll
     for (int kb = 0; kb < KBW; ++kb) acc[kb] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const int r16 = tid >> 4, q16 = tid & 15;         // staging: row r16 of the chunk, float4 columns q16 + 16 it
-    v4f gv, cv[NV];
-    auto prefetch = [&](int ch) {
-        gv = *reinterpret_cast<const v4f *>(a.G + ((size_t)(ch >> 1) * nJ + bblk) * 4096 + (ch & 1) * 2048 + (size_t)tid * 4);
+    // register sets of chunks in flight: one (the chunk after the one being multiplied), or DEEP: two -- chunk ch + 3 is
+    // requested while chunk ch is multiplied and parked two chunks later, i.e. two chunk times (~4 us) to cover the load latency
+    constexpr int NSET = DEEP ? 2 : 1;
+    v4f gv[NSET], cv[NSET][NV];
+    auto prefetch = [&](int ch, auto set) {
+        constexpr int S = decltype(set)::value;
+        gv[S] = *reinterpret_cast<const v4f *>(a.G + ((size_t)(ch >> 1) * nJ + bblk) * 4096 + (ch & 1) * 2048 + (size_t)tid * 4);
         const float *cm = a.Cm + ((size_t)ch * NC + r16) * (16 * KB);
 #pragma unroll
-        for (int it = 0; it < NV; ++it) cv[it] = *reinterpret_cast<const v4f *>(cm + 4 * (q16 + 16 * it));
+        for (int it = 0; it < NV; ++it) cv[S][it] = *reinterpret_cast<const v4f *>(cm + 4 * (q16 + 16 * it));
     };
-    auto park = [&](int buf) {
+    auto park = [&](int buf, auto set) {
+        constexpr int S = decltype(set)::value;
         float *cs = Cs + buf * PAIR, *gt = Gt + buf * PAIR;
-        *reinterpret_cast<v4f *>(gt + (tid >> 4) * LDGT + 4 * (tid & 15)) = gv;       // float4 number tid: candidate tid >> 4
+        *reinterpret_cast<v4f *>(gt + (tid >> 4) * LDGT + 4 * (tid & 15)) = gv[S];    // float4 number tid: candidate tid >> 4
 #pragma unroll
-        for (int it = 0; it < NV; ++it) *reinterpret_cast<v4f *>(cs + r16 * LDK + 4 * (q16 + 16 * it)) = cv[it];
+        for (int it = 0; it < NV; ++it) *reinterpret_cast<v4f *>(cs + r16 * LDK + 4 * (q16 + 16 * it)) = cv[S][it];
     };
-    if (ch_lo < ch_hi) {
-        prefetch(ch_lo);
-        park(0);
-        if (ch_lo + 1 < ch_hi) prefetch(ch_lo + 1);
-    }
-    for (int ch = ch_lo; ch < ch_hi; ++ch) {
-        const int buf = (ch - ch_lo) & 1;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, DEEP ? 1 : 0>;
+    // one chunk: `buf` = the pair chunk ch was parked in; the next chunk goes from register set `nxt` into the other pair, and
+    // the freed set takes chunk ch + 1 + NSET
+    auto step = [&](int ch, int buf, auto nxt) {
         __syncthreads();                       // chunk ch is parked; the other pair's readers (chunk ch - 1) are done
         const bool more = ch + 1 < ch_hi;
         if (ks == 0 && more) {                 // this wave group parks its share of chunk ch + 1 first ...
-            park(buf ^ 1);
-            if (ch + 2 < ch_hi) prefetch(ch + 2);
+            park(buf ^ 1, nxt);
+            if (ch + 1 + NSET < ch_hi) prefetch(ch + 1 + NSET, nxt);
         }
-        // A[i = b][slot s, step t] = G^T[n = 8s + t][b = 16wq + c] ; B[slot][k] = C[n = 8s + t][256 ks + k]
+        // A[i = b][slot s, step t] = G^T[n = 8s + t][b = 16wq + c] ; B[slot][k] = C[n = 8s + t][16 KBW ks + k]
         grad_product<KBW, false, LDK, 0, 8>(acc, Gt + buf * PAIR + 8 * s * LDGT + 16 * wq + c, LDGT,
                                             Cs + buf * PAIR + 8 * s * LDK + 16 * KBW * ks, c);
         if (ks == 1 && more) {                 // ... the other one after its MFMAs: a SIMD's two waves take turns
-            park(buf ^ 1);
-            if (ch + 2 < ch_hi) prefetch(ch + 2);
+            park(buf ^ 1, nxt);
+            if (ch + 1 + NSET < ch_hi) prefetch(ch + 1 + NSET, nxt);
         }
+    };
+    if (ch_lo < ch_hi) {
+        prefetch(ch_lo, S0{});
+        park(0, S0{});
+        if (DEEP) {
+            if (ch_lo + 1 < ch_hi) prefetch(ch_lo + 1, S1{});
+            if (ch_lo + 2 < ch_hi) prefetch(ch_lo + 2, S0{});
+        } else if (ch_lo + 1 < ch_hi) {
+            prefetch(ch_lo + 1, S0{});
+        }
+    }
+    // (chunk ch_lo + j: LDS pair j & 1; its registers were set (j & 1) of DEEP, else the one set)
+    for (int ch = ch_lo; ch < ch_hi; ch += 2) {
+        step(ch, 0, S1{});
+        if (ch + 1 < ch_hi) step(ch + 1, 1, S0{});
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -812,9 +830,13 @@ template <int KB>
 static hipError_t launch_dq8k_t(const DqArgs &a, int grid_x, hipStream_t st)
 {
     const size_t sh = (size_t)2 * (32 * lds_ld(16 * KB) + 32 * LDGT) * sizeof(float);
-    static LdsOptIn lds_opt_in;
-    if (hipError_t e = ensure_dynamic_lds(lds_opt_in, reinterpret_cast<const void *>(dq8k_kernel<KB>), sh); e != hipSuccess) return e;
-    hipLaunchKernelGGL(dq8k_kernel<KB>, dim3(grid_x), dim3(512), sh, st, a);
+    // two chunks of loads in flight per thread at KB = 16 (cfg4 shard: 1059 -> 1046 us per range; at KB = 32 the 36 extra
+    // registers cost more than the latency they cover: 53.6 -> 54.2 us at cfg3); OKGE_DQ_DEEP=0 / 1 overrides
+    static const bool deep = [] { const char *e = getenv("OKGE_DQ_DEEP"); return e ? atoi(e) != 0 : KB == 16; }();
+    auto k = deep ? dq8k_kernel<KB, true> : dq8k_kernel<KB, false>;
+    static LdsOptIn lds_opt_in[2];
+    if (hipError_t e = ensure_dynamic_lds(lds_opt_in[deep], reinterpret_cast<const void *>(k), sh); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid_x), dim3(512), sh, st, a);
     return hipGetLastError();
 }
 
