@@ -5,9 +5,11 @@ Same class names, constructor keywords, method names and tensor conventions as t
 ids are int32 ``(b, 1)`` (or ``(N,)`` for candidates), scores come back ``(b, N)`` fp32, state-dict keys are
 ``entity_embedding.weight`` and ``relation_embedding.weight``.  What differs:
 
-* every arithmetic step runs in libokge_hip.so (no ATen math); the methods return plain tensors without an
-  autograd graph.  Gradients are produced by ``trainer.AddLossModule`` (fused forward + loss + backward), which
-  is how the reference's Trainer consumes the model (openkge/trainer.py:142,206-234);
+* every forward runs in libokge_hip.so (no ATen math).  Training gradients are produced by ``trainer.AddLossModule``
+  (fused forward + loss + backward), which is how the reference's Trainer consumes the model
+  (openkge/trainer.py:142,206-234).  Called directly WITH gradients enabled (a user's own loss on ``sp_prefix_score`` /
+  ``po_prefix_score`` / ``forward`` / ``_score`` / ``encode_*``) the methods return tensors with an autograd graph
+  (``autograd_score``: HIP forward, GEMM + chain-rule backward); under ``torch.no_grad()`` they take the fused id path;
 * the fused path (gather + dropout inside the tile kernels) covers the lookup embedder with batch_norm / projection /
   normalize / l2_reg off -- every BASELINE config.  With one of those `_encode` variants on (model.py:463-479) the
   embedder FALLS THROUGH to torch for the encode (the reference's own op sequence, differentiable) and the encoded rows
@@ -20,8 +22,13 @@ from __future__ import annotations
 
 import torch
 
+from . import autograd_score as AG
 from . import hotpath as H
 from ._native import OkgeError
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 PAD = 0   # openkge/index_mapper.py:14  (ids 0, 1 are reserved; real ids start at 2)
 
@@ -47,8 +54,10 @@ class RelationScorer(RelationModel):
         return self.triple_score(self.encode_subj(subj), self.encode_rel(rel), self.encode_obj(obj), **kwargs)
 
     def triple_score(self, subj, rel, obj, **kwargs):
-        """(b, 1) scores of encoded triples, Hadamard form (model.py:178-179, :231-238, :276).  Inference helper:
-        the reference trains through the prefix path only (trainer.py:59-64), so no gradient is defined here."""
+        """(b, 1) scores of encoded triples, Hadamard form (model.py:178-179, :231-238, :276); with gradients enabled and
+        rows that carry a graph, the same form in differentiable torch ops"""
+        if _wants_grad(subj, rel, obj):
+            return AG.triple_score(self.scorer_name, subj, rel, obj)
         return self.engine().score_triples(self.scorer_name, subj, rel, obj)
 
     def sp_prefix_score(self, subj=None, rel=None, many_obj=None):
@@ -67,7 +76,13 @@ class RelationScorer(RelationModel):
         if not prefix:
             return self.triple_score(subj, rel, obj)
         eng = self.engine()
-        subj, rel, obj = subj.detach(), rel.detach(), obj.detach()      # inference helper: gradients come from AddLossModule
+        if not sp and not po:
+            raise Exception      # model.py:217-218, :273-274
+        if _wants_grad(subj, rel, obj):     # a graph for the caller's own loss (AddLossModule never comes through here)
+            flat = lambda t: t.reshape(-1, t.shape[-1])      # noqa: E731
+            ent, cand = (flat(subj), flat(obj)) if sp else (flat(obj), flat(subj))
+            return AG.PrefixScoreFn.apply(ent, flat(rel), cand, eng, self.scorer_name, bool(sp))
+        subj, rel, obj = subj.detach(), rel.detach(), obj.detach()
         rel = rel.reshape(-1, rel.shape[-1]).contiguous()
         b = rel.shape[0]
         ar = torch.arange(b, dtype=torch.int32, device=rel.device)
@@ -78,7 +93,7 @@ class RelationScorer(RelationModel):
             ent, cand = obj.reshape(-1, obj.shape[-1]).contiguous(), subj.reshape(-1, subj.shape[-1]).contiguous()
             batch = H.PrefixBatch(po_rel=ar, po_obj=ar)
         else:
-            raise Exception      # model.py:217-218, :273-274
+            raise Exception
         batch.cand_table, batch.cand_first, batch.n_cand = cand, 0, cand.shape[0]
         return eng.score(ent, rel, self.scorer_name, batch)
 
@@ -217,9 +232,15 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
             return self._encode_torch(slot_item, self.entity_embedding, proj, self.input_dropout, self.dropout,
                                       self.bn_e if self.batch_norm else None, lookup)
         eng = self.engine()
+        weight = (self.relation_embedding if relation else self.entity_embedding).weight
         if not lookup:                    # model.py:459-460: already rows, only dropout applies
+            if _wants_grad(slot_item):
+                return AG.MaskRowsFn.apply(slot_item, eng, self.dropout_spec(stream, relation))
             rows = slot_item.contiguous()
             return eng.encode_rows(rows, None, 0, rows.shape[0], self.dropout_spec(stream, relation))
+        if _wants_grad(weight):
+            ids = slot_item.reshape(-1)
+            return AG.EncodeRowsFn.apply(weight, ids, 0, int(ids.numel()), eng, self.dropout_spec(stream, relation))
         return eng.encode_rows(table, slot_item.reshape(-1), drop=self.dropout_spec(stream, relation))
 
     def encode_subj(self, subj, lookup=True):
@@ -235,6 +256,10 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
         if self.encode_in_torch:           # model.py:512-514: encode(weight[min_size:], lookup=False)
             w = (self.relation_embedding if relation else self.entity_embedding).weight[min_size:].contiguous()
             return self._encode(None, w, stream, relation, lookup=False, which=which)
+        weight = (self.relation_embedding if relation else self.entity_embedding).weight
+        if _wants_grad(weight):
+            return AG.EncodeRowsFn.apply(weight, None, min_size, table.shape[0] - min_size, self.engine(),
+                                         self.dropout_spec(stream, relation))
         return self.engine().encode_rows(table, None, min_size, table.shape[0] - min_size,
                                          self.dropout_spec(stream, relation))
 
@@ -265,8 +290,11 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
     # -- fused prefix scoring (ids in, scores out) -----------------------------------------------------
     def _prefix_score(self, batch: H.PrefixBatch, many=None):
         eng = self.engine()
-        if self.encode_in_torch:           # variants: torch encode (model.py:52-74's own call order), HIP scorer
-            if batch.sp_subj is not None:
+        with_graph = not self.encode_in_torch and _wants_grad(self.entity_embedding.weight, self.relation_embedding.weight, many)
+        if with_graph and self.training:
+            self.dropout_step += 1         # fresh masks per call, as each of the reference's encode calls draws them
+        if self.encode_in_torch or with_graph:   # torch encode of the variants / a graph for the caller's loss: the
+            if batch.sp_subj is not None:        # reference's own call order (model.py:52-74), HIP scorer
                 subj, rel = self.encode_subj(batch.sp_subj), self.encode_rel(batch.sp_rel)
                 return self._score(subj, rel, self.get_all_obj() if many is None else many, prefix=True, sp=True, po=False)
             if many is None:

@@ -1,0 +1,141 @@
+"""The plugin methods called WITH gradients enabled, outside AddLossModule (a user's own loss on `sp_prefix_score` /
+`po_prefix_score` / `forward` / `_score`): HIP forward + the GEMM / chain-rule backward of autograd_score.py, against the
+reference's op sequence differentiated by ATen -- oracle/torch_twin.TwinModel (openkge/model.py:198-240, :268-278,
+:455-480; pinned by tests/test_oracle_golden.py) in FLOAT64 on the CPU.  Tolerances: scores 2e-5 absolute (fp32 sums of
+d <= 200 terms of size 0.1), gradients 1e-4 of the largest gradient entry."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_twin
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(kind, n_ent, n_rel, d, seed, dropout=0.0):
+    from open_knowledge_graph_embeddings_amd.dataset import EntityRelationDatasetMeta
+    from open_knowledge_graph_embeddings_amd.model import Models
+    rng = np.random.default_rng(seed)
+    E = (rng.standard_normal((n_ent, d)) * 0.3).astype(np.float32)
+    R = (rng.standard_normal((n_rel, d)) * 0.3).astype(np.float32)
+    name = "LookupComplexRelationModel" if kind == "complex" else "LookupDistmultRelationModel"
+    m = getattr(Models, name)(entity_slot_size=d, init_std=0.1, sparse=False, input_dropout=dropout,
+                              train_data=EntityRelationDatasetMeta(entities_size=n_ent, relations_size=n_rel))
+    twin = torch_twin.TwinModel(kind, n_ent, n_rel, d).double()
+    with torch.no_grad():
+        m.entity_embedding.weight.copy_(torch.from_numpy(E))
+        m.relation_embedding.weight.copy_(torch.from_numpy(R))
+        twin.entity_embedding.weight.copy_(torch.from_numpy(E).double())
+        twin.relation_embedding.weight.copy_(torch.from_numpy(R).double())
+    return m.cuda(), twin, rng
+
+
+def _ids(rng, lo, hi, n):
+    return torch.from_numpy(rng.integers(lo, hi, (n, 1)).astype(np.int32))
+
+
+def _compare_grads(m, twin):
+    for name in ("entity_embedding", "relation_embedding"):
+        got, ref = getattr(m, name).weight.grad, getattr(twin, name).weight.grad
+        assert got is not None, name
+        ref = ref.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-4 * np.abs(ref).max() + 1e-12, err_msg=name)
+
+
+@pytest.mark.parametrize("kind,d", [("complex", 16), ("distmult", 24), ("complex", 200)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_prefix_scores_carry_a_graph(okge_lib, kind, d, mode):
+    """own loss on sp_prefix_score (all objects) + po_prefix_score (all subjects): scores and both tables' gradients"""
+    m, twin, rng = _pair(kind, 300, 12, d, seed=d)
+    getattr(m, mode)()
+    b = 9
+    subj, rel_s, rel_o, obj = _ids(rng, 2, 300, b), _ids(rng, 2, 12, b), _ids(rng, 2, 12, b), _ids(rng, 2, 300, b)
+    W1 = torch.from_numpy(rng.standard_normal((b, 298)))
+    W2 = torch.from_numpy(rng.standard_normal((b, 298)))
+    own = lambda x1, x2, w1, w2: (torch.tanh(x1) * w1).sum() + (x2 * x2 * w2).sum()       # noqa: E731
+    x_sp = m.sp_prefix_score(subj.cuda(), rel_s.cuda())
+    x_po = m.po_prefix_score(rel_o.cuda(), obj.cuda())
+    assert x_sp.requires_grad and x_po.requires_grad and x_sp.shape == (b, 298)
+    own(x_sp, x_po, W1.float().cuda(), W2.float().cuda()).backward()
+    cand = twin.enc_ent(torch.arange(2, 300))
+    r_sp = twin.score(twin.enc_ent(subj), twin.enc_rel(rel_s), cand, sp=True)
+    r_po = twin.score(twin.enc_ent(obj), twin.enc_rel(rel_o), cand, sp=False)
+    own(r_sp, r_po, W1, W2).backward()
+    np.testing.assert_allclose(x_sp.detach().cpu().numpy(), r_sp.detach().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(x_po.detach().cpu().numpy(), r_po.detach().numpy(), rtol=0, atol=2e-5)
+    _compare_grads(m, twin)
+    # and without a graph the fused id path gives the same scores
+    with torch.no_grad():
+        y = m.sp_prefix_score(subj.cuda(), rel_s.cuda())
+    assert not y.requires_grad
+    np.testing.assert_allclose(y.cpu().numpy(), x_sp.detach().cpu().numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("kind", ["complex", "distmult"])
+def test_shared_candidates_and_triples_carry_a_graph(okge_lib, kind):
+    """precompute_batch_shared_inputs (a candidate id list WITH repeats: their gradients add up) -> *_prefix_score(many_*),
+    `_score` on encoded rows, and forward(subj, rel, obj) (Hadamard triple scores)"""
+    m, twin, rng = _pair(kind, 120, 9, 32, seed=5)
+    m.train()
+    b = 7
+    subj, rel, obj = _ids(rng, 2, 120, b), _ids(rng, 2, 9, b), _ids(rng, 2, 120, b)
+    cand_ids = torch.from_numpy(np.concatenate([rng.integers(2, 120, 40), [5, 5, 7]]).astype(np.int32))
+    W = torch.from_numpy(rng.standard_normal((b, 43)))
+    Wt = torch.from_numpy(rng.standard_normal((b, 1)))
+    shared = m.precompute_batch_shared_inputs(cand_ids.cuda())
+    assert shared.requires_grad
+    x = m.sp_prefix_score(subj.cuda(), rel.cuda(), shared) + m.po_prefix_score(rel.cuda(), obj.cuda(), shared)
+    x2 = m._score(m.encode_subj(subj.cuda()), m.encode_rel(rel.cuda()), shared, prefix=True, sp=True, po=False)
+    t = m(subj.cuda(), rel.cuda(), obj.cuda())
+    assert t.shape == (b, 1) and t.requires_grad
+    ((x * W.float().cuda()).sum() + (x2 * x2).sum() + (t * Wt.float().cuda()).sum()).backward()
+    c = twin.enc_ent(cand_ids)
+    s, r, o = twin.enc_ent(subj), twin.enc_rel(rel), twin.enc_ent(obj)
+    rx = twin.score(s, r, c, sp=True) + twin.score(o, r, c, sp=False)
+    rx2 = twin.score(s, r, c, sp=True)
+    if kind == "distmult":
+        rt = (s * o * r).sum(1, keepdim=True)
+    else:                                                                   # model.py:231-238
+        r1, r2 = r.chunk(2, 1)
+        o1, o2 = o.chunk(2, 1)
+        rt = (torch.cat((s, s), 1) * torch.cat((o, o2, o1), 1) * torch.cat((r1, r, -r2), 1)).sum(1, keepdim=True)
+    ((rx * W).sum() + (rx2 * rx2).sum() + (rt * Wt).sum()).backward()
+    np.testing.assert_allclose(x.detach().cpu().numpy(), rx.detach().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(t.detach().cpu().numpy(), rt.detach().numpy(), rtol=0, atol=2e-5)
+    _compare_grads(m, twin)
+    with pytest.raises(Exception):
+        m._score(shared, shared, shared, prefix=True)                        # neither sp nor po (model.py:217-218)
+
+
+def test_dropout_masks_of_forward_and_backward_agree(okge_lib):
+    """training mode with input dropout: the gradient must be the derivative of THE scores that were returned (same Philox
+    masks in the backward).  The scores are linear in the entity table for fixed masks, so a finite difference along a
+    random direction is exact up to rounding."""
+    m, _, rng = _pair("complex", 200, 8, 64, seed=11, dropout=0.4)
+    m.train()
+    b = 16
+    subj, rel = _ids(rng, 2, 200, b).cuda(), _ids(rng, 2, 8, b).cuda()
+    W = torch.from_numpy(rng.standard_normal((b, 198)).astype(np.float32)).cuda()
+    D = torch.from_numpy(rng.standard_normal((200, 64)).astype(np.float32)).cuda()
+
+    def run():
+        m.dropout_step = 41                                                  # the call advances it: same masks every time
+        return m.sp_prefix_score(subj, rel)
+    x = run()
+    (x * W).sum().backward()
+    g = m.entity_embedding.weight.grad.clone()
+    # dropped components: rows of the gradient have exact zeros where the mask dropped the candidate's column
+    assert 0.2 < float((g[2:] == 0).float().mean()) < 0.6
+    # the scores are BILINEAR in the entity table (prefix entity x candidate): central difference of the quadratic is exact
+    # (run() stays outside no_grad: the graph path and the fused id path number their dropout steps differently)
+    eps = 1e-2
+    E0 = m.entity_embedding.weight.detach().clone()
+    m.entity_embedding.weight.data.copy_(E0 + eps * D)
+    xp = run().detach().double()
+    m.entity_embedding.weight.data.copy_(E0 - eps * D)
+    xm = run().detach().double()
+    m.entity_embedding.weight.data.copy_(E0)
+    assert torch.equal(run().detach(), x.detach())                          # same masks: the same scores again
+    fd = float(((xp - xm) * W.double()).sum() / (2 * eps))
+    an = float((g.double() * D.double()).sum())
+    assert abs(fd - an) <= 2e-4 * max(1.0, abs(an)), (fd, an)

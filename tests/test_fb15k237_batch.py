@@ -75,7 +75,8 @@ def test_hip_on_fb15k237_batch(okge_lib):
     m = m.cuda().eval()
     po_rel, po_obj, sp_subj, sp_rel = (dev(z[k]) for k in ("po_rel", "po_obj", "sp_subj", "sp_rel"))
     # 1. the model API, as the reference's evaluation calls it
-    x = torch.cat([m.po_prefix_score(po_rel, po_obj), m.sp_prefix_score(sp_subj, sp_rel)], 0)
+    with torch.no_grad():                                                   # (trainer.py:366)
+        x = torch.cat([m.po_prefix_score(po_rel, po_obj), m.sp_prefix_score(sp_subj, sp_rel)], 0)
     check_scores(x.cpu().numpy(), z)
     # 2. filtered ranks from CSR answer groups / filter
     hp = H.HotPath("cuda:0")

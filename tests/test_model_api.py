@@ -68,7 +68,8 @@ def test_metric_meters():
 # --------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", golden_names("g1_scores_"))
-def test_prefix_score_methods(name):
+@torch.no_grad()                          # as the reference's evaluation calls them (trainer.py:366); with gradients enabled
+def test_prefix_score_methods(name):      # the methods return tensors with a graph (tests/test_autograd_surface.py)
     z = golden(name)
     cls = "LookupComplexRelationModel" if "complex" in name else "LookupDistmultRelationModel"
     m = make_model(cls, z["E"], z["R"], "cuda:0").eval()
@@ -92,6 +93,7 @@ def test_prefix_score_methods(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", golden_names("g1_triples_"))
+@torch.no_grad()
 def test_forward_triple_score(name):
     """model(subj, rel, obj) = triple_score(encode_subj, encode_rel, encode_obj) (model.py:43-50)."""
     z = golden(name)
@@ -155,6 +157,7 @@ def test_compute_metrics(name):
 
 
 @pytest.mark.gpu
+@torch.no_grad()
 def test_dropout_training_is_deterministic_per_step_and_unbiased():
     """input_dropout in training mode: same (seed, step) -> same result; mean keep rate matches 1-p."""
     z = golden("g2_loss_complex_bce_d200")
