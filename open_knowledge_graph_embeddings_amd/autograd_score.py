@@ -90,6 +90,7 @@ class EncodeRowsFn(torch.autograd.Function):
             d_table.index_add_(0, ids.reshape(-1).long(), g)
         else:
             d_table[ctx.first_id:ctx.first_id + ctx.n] = g
+        d_table[0].zero_()              # nn.Embedding(padding_idx=PAD = 0), model.py:390-391: the pad row gets no gradient
         return d_table, None, None, None, None, None
 
 

@@ -366,12 +366,32 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
         eng = self.engine()
         ids = ids.reshape(-1).to(torch.int32).contiguous()
         n, d = ids.numel(), self.slot_size
+        emb, tok, bn = (self.relation_embedding, self.relation_token_ids, self.relation_batchnorm) if relation else \
+            (self.entity_embedding, self.entity_token_ids, self.entity_batchnorm)
+        p = (self.relation_dropout if relation else self.entity_dropout) if self.training else 0.0
+        if torch.is_grad_enabled() and (emb.weight.requires_grad or (bn is not None and bn.weight.requires_grad)):
+            # called with gradients enabled outside AddLossModule (a caller's own loss): the reference's op sequence in
+            # torch (model.py:762-786; differentiable, the BatchNorm1d module keeps its own running statistics), dropout by
+            # the Philox mask kernel (autograd_score.MaskRowsFn)
+            from . import autograd_score as AG
+            tokens = tok[ids.long()].long()
+            embedded = emb(tokens)
+            if self.pool == 'max':
+                encoded, _ = embedded.max(dim=1)
+            elif self.pool == 'mean':
+                encoded = embedded.sum(dim=1) / ((tokens > 0).float().sum(1, keepdim=True) + 1e-12)
+            else:
+                encoded = embedded.sum(dim=1)
+            if bn is not None:
+                encoded = bn(encoded.contiguous())
+            if p > 0:
+                encoded = AG.MaskRowsFn.apply(encoded, eng, H.DropoutSpec(p, self.dropout_seed, stream, self.dropout_step))
+            return encoded.unsqueeze(1)
         slot = self._slot(relation)
         raw = torch.empty((n, d), device=ids.device)
         out = torch.empty_like(raw) if slot.bn is not None else raw
         saved = torch.empty(4 * d, device=ids.device) if slot.bn is not None else None
         self._pool_engine.encode(slot, ids, 0, n, self.training, raw, out, saved)
-        p = (self.relation_dropout if relation else self.entity_dropout) if self.training else 0.0
         if p > 0:
             out = eng.encode_rows(out, None, 0, n, H.DropoutSpec(p, self.dropout_seed, stream, self.dropout_step))
         return out.unsqueeze(1)
@@ -396,8 +416,9 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
             super().train(False)                       # the reference calls self.eval() here and stays in eval mode
             dev = self.entity_embedding.weight.device
             ar = lambda n: torch.arange(n, dtype=torch.int32, device=dev)      # noqa: E731
-            self.entity_embedding_from_tokens = self._encode(ar(self.train_data.entities_size), False, H.STREAM_CAND).squeeze(1)
-            self.relations_embedding_from_tokens = self._encode(ar(self.train_data.relations_size), True, H.STREAM_SP_REL).squeeze(1)
+            with torch.no_grad():                      # model.py:682: the precomputed tables carry no graph
+                self.entity_embedding_from_tokens = self._encode(ar(self.train_data.entities_size), False, H.STREAM_CAND).squeeze(1)
+                self.relations_embedding_from_tokens = self._encode(ar(self.train_data.relations_size), True, H.STREAM_SP_REL).squeeze(1)
             del was_training
 
     def get_all_subj(self):

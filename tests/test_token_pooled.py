@@ -60,6 +60,7 @@ def test_train_forward_backward_matches_reference(okge_lib, name):
 
 
 @pytest.mark.parametrize("name", golden_names("g9_unigram_"))
+@torch.no_grad()                           # the reference's evaluation (trainer.py:366); with gradients: test_autograd_surface.py
 def test_model_api_eval_tables_and_scores(okge_lib, name):
     """precompute_embeddings_from_tokens + sp/po_prefix_score in eval mode, after the training step's running-stat
     update (the fixture's eval outputs were taken after one training forward)."""
