@@ -216,10 +216,11 @@ bool make_geometry(int B, int N, int d, Geometry &g)
         rt = std::max<int64_t>(1, std::min<int64_t>(rt, g.tiles));
         g.range_tiles = (int)rt;
         g.n_ranges = (g.tiles + g.range_tiles - 1) / g.range_tiles;
-        if (g.n_ranges > 1 && g.KB <= 16 && rt >= 256) {
-            // slot sizes up to 256 run one workgroup per CU and tile: ranges of whole rounds (a multiple of 256 tiles), so
-            // that only the LAST range ends in a partial round -- the one the tail split below shortens
-            g.range_tiles = (int)(rt / 256 * 256);
+        const int cus = cu_count();
+        if (g.n_ranges > 1 && g.KB <= 16 && rt >= cus) {
+            // slot sizes up to 256 run one workgroup per CU and tile: ranges of whole rounds (a multiple of the CU count: 256
+            // tiles on an MI355X), so that only the LAST range ends in a partial round -- the one the tail split below shortens
+            g.range_tiles = (int)(rt / cus * cus);
         } else {
             g.range_tiles = (g.tiles + g.n_ranges - 1) / g.n_ranges;              // even out the ranges
         }
@@ -233,7 +234,7 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     // (slot sizes above 256: fused_tile64k_kernel, candidate tile in registers; OKGE_TILE_W=32 selects the round-1/2 cut)
     g.tile_w = env_int("OKGE_TILE_W", 64) == 32 ? 32 : 64;
     g.ktiles = g.tiles * (NT / g.tile_w);
-    const int slots = (g.tile_w == 64 || g.KB > 16) ? 256 : 512;       // one workgroup per CU, except the 32-wide cut at d <= 256
+    const int slots = (g.tile_w == 64 || g.KB > 16) ? cu_count() : 2 * cu_count();   // one workgroup per CU, except the 32-wide cut at d <= 256
     // fill the CUs: if there are few candidate tiles, split the batch rows across blockIdx.y.  Cost of a split into c:
     // (rounds of workgroups over the slots) x (row blocks per workgroup + 1) -- the "+ 1" is a workgroup's fixed cost, the
     // candidate gather and the gradient write-back, about one 64-row block (profiles/round2_ablation.md §1) -- plus the c
@@ -276,7 +277,7 @@ bool make_geometry(int B, int N, int d, Geometry &g)
     // dQ kernel: (batch block, candidate range) workgroups: 8-wave workgroups, one per CU (d <= 256), else 4-wave, two per CU
     // (slot sizes above 256: dq8k_kernel, 32-candidate chunks double-buffered; OKGE_DQ8K=0 selects dq_kernel<32>)
     g.dq8 = (g.KB <= 16 && env_int("OKGE_DQ8", 1) != 0) || (g.KB == 32 && env_int("OKGE_DQ8K", 1) != 0);
-    int ns = std::max(1, (g.dq8 ? 256 : 512) / bblks);
+    int ns = std::max(1, (g.dq8 ? cu_count() : 2 * cu_count()) / bblks);
     if (ns >= 8) ns = ns / 8 * 8;   // workgroups of one candidate range then share an XCD (blockIdx % 8)
     ns = env_int("OKGE_DQ_SPLIT", ns);
     ns = std::max(1, std::min(ns, g.range_tiles));
@@ -361,7 +362,7 @@ FusedArgs tile_window(const FusedArgs &base, const Geometry &g, int t0)
 hipError_t launch_score_sweep(const Geometry &g, const FusedArgs &a0, int tiles, hipStream_t st, int mode = MODE_SCORE)
 {
     if (g.KB <= 16) {
-        const TailSplit ts = a0.b_per_block >= g.Bpad ? tail_split(tiles, g.Bpad, 256) : TailSplit{0, 0, g.Bpad};
+        const TailSplit ts = a0.b_per_block >= g.Bpad ? tail_split(tiles, g.Bpad, cu_count()) : TailSplit{0, 0, g.Bpad};
         if (ts.split < 2) return launch_fused(mode, a0, tiles, 1, st);
         FusedArgs am = a0;
         am.N = (tiles - ts.tiles) * NT;
