@@ -349,6 +349,16 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
             const int ybit = 16 * (blk & 1) + c;
             const bool edge = col_edge || b0 + BC64 > b_end;      // uniform: only the last tile / a partial last chunk
             const bool nvalid = n0 + 16 * blk + c < a.N;
+            // BCE, LOGPROD: the log1p terms of the lane's 8 scores as ONE log of the product of (1 + e^-|x|) (each factor in
+            // (1, 2]) -- v_log_f32 is a quarter-rate instruction and fp32 MFMA and VALU exclude each other on a SIMD, so the
+            // epilogue's VALU time comes straight out of the MFMA time -- and G = sig * inv_norm - y * inv_norm as one fma.
+            // cfg4 shard (KB = 16): 2197 -> 2142 us per range, cfg5 302 -> 295 us.  NOT at KB = 13 with the register-resident
+            // operand: that instance sits at 256 registers and the two extra accumulators cost 18 more spilled dwords
+            // (S-FB 72.9 -> 73.8 us; one log per FOUR scores and the old G arithmetic spill just as much), so it keeps one
+            // log per score.
+            constexpr bool LOGPROD = !(REGC && KB > 8);
+            float lin = 0.f, prod = 1.f;
+            const float gy_pos = -a.y_pos * a.inv_norm, gy_neg = -a.y_neg * a.inv_norm;
 #pragma unroll
             for (int rg = 0; rg < 2; ++rg) {
                 const v4f x = rg == 0 ? x0 : x1;
@@ -362,9 +372,17 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
                         // v_exp_f32 / v_rcp_f32 / v_log_f32 (1 ulp each); 1 + e is in (1, 2]
                         const float y = pos ? a.y_pos : a.y_neg;
                         const float e = __builtin_amdgcn_exp2f(-fabsf(xv) * LOG2E);
-                        const float ope = 1.f + e;
+                        float ope = 1.f + e;
                         const float rcp = __builtin_amdgcn_rcpf(ope);
                         const float sig = xv >= 0.f ? rcp : e * rcp;
+                        if (LOGPROD) {
+                            l = fmaxf(xv, 0.f) - xv * y;
+                            if (edge && !(nvalid && b0 + 32 * h + 16 * rg + 4 * s + i < b_end)) { l = 0.f; ope = 1.f; }
+                            lin += l;
+                            prod *= ope;
+                            g4[rg][i] = fmaf(sig, a.inv_norm, pos ? gy_pos : gy_neg);
+                            continue;
+                        }
                         l = fmaxf(xv, 0.f) - xv * y + __builtin_amdgcn_logf(ope) * LN2;
                         gg = sig - y;
                     } else {
@@ -381,6 +399,7 @@ __global__ __launch_bounds__(T64_THREADS, 2) void fused_tile64_kernel(const Fuse
                     g4[rg][i] = gg * a.inv_norm;
                 }
             }
+            if (MODE == MODE_TRAIN_BCE && LOGPROD) lsum += lin + __builtin_amdgcn_logf(prod) * LN2;
         }
         if (REGC && b0 + BC64 < b_end) {
             // park the next chunk in the other buffer (its last readers finished before this chunk's barrier) and request the
