@@ -140,6 +140,11 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
  *               okge_collate_batch emits): their gradient rows are written without atomics.  Without the flag an
  *               explicit id list may repeat entities (precompute_batch_shared_inputs takes any list). */
 #define OKGE_TRAIN_UNIQUE_CANDIDATES 4
+/*               OKGE_TRAIN_DISTINCT_PREFIX_ROWS -- every prefix entity id and every prefix relation id of the batch occurs
+ *               ONCE and no prefix entity is also a candidate (the "virtual tables" of already encoded rows that the
+ *               token-pooled embedder and the embedder variants score: row = position, model.py:762-786 / :463-479):
+ *               their gradient rows are STORED, not accumulated -- no float atomics, and the caller need not clear them. */
+#define OKGE_TRAIN_DISTINCT_PREFIX_ROWS 8
 int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch,
                                 const okge_candidates *cand, const okge_positives *pos,
                                 int32_t loss_kind, float label_smoothing, double normalizer, int32_t flags,

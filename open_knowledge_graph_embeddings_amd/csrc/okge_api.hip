@@ -649,7 +649,8 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         ScopedTimer tm("prefix_backward", st);      // + the deterministic loss reduction (one extra workgroup)
         const PrefixDev p = to_dev(*batch, t, sh);
         e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, nullptr, dE, dR,
-                                   a.loss_partial, n_loss_partials, loss_out, st);
+                                   a.loss_partial, n_loss_partials, loss_out, st, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr,
+                                   (flags & OKGE_TRAIN_DISTINCT_PREFIX_ROWS) ? 1 : 0);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
     }
     return OKGE_OK;

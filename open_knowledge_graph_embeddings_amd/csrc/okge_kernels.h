@@ -109,7 +109,7 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
                                   float *dR, const double *loss_partials, int n_partials, double *loss_out,
                                   hipStream_t st, const int32_t *rel_order = nullptr, const int32_t *rel_seg_ptr = nullptr,
                                   int n_rel_seg = 0, const int32_t *ent_order = nullptr, const int32_t *ent_seg_ptr = nullptr,
-                                  int n_ent_seg = 0, float *grad_rows = nullptr);
+                                  int n_ent_seg = 0, float *grad_rows = nullptr, int distinct = 0);
 hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
 hipError_t launch_kl_count_pos(const int32_t *pos_row, int nnz, int Bpad, float *row_ysum, hipStream_t st);
 hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, float *run, int first, int last, float *row_lse,

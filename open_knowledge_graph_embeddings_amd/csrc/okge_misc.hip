@@ -241,10 +241,15 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
                                                               int d, int scorer, const PrefixDev p,
                                                               const float *__restrict__ slab, int nsplit, int Bpad,
                                                               int ldq, const float *__restrict__ ent_rows,
-                                                              float *__restrict__ dE, float *__restrict__ dR)
+                                                              float *__restrict__ dE, float *__restrict__ dR, int distinct)
 {
     // ent_rows (sharded path): the already masked prefix entity rows of ALL prefixes, so every rank forms the full
     // relation gradient; the entity gradient is scattered by the owner only.
+    // distinct (OKGE_TRAIN_DISTINCT_PREFIX_ROWS): every prefix id occurs once -- its gradient row is stored, not accumulated
+    auto put = [&](float *dst, float v) {
+        if (distinct) *dst = v;
+        else atomicAdd(dst, v);
+    };
     const int b = blockIdx.x;
     const RowSrc rs = row_source(p, b);
     if (!ent_rows && !rs.owned) return;
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
             for (int sidx = 0; sidx < nsplit; ++sidx) dq += sl[sidx * split_stride + k];
             const float me = drop_mult1(de, rs.pos, k, d), mr = drop_mult1(dr, rs.pos, k, d);
             const float ev = e_masked ? e[k] : e[k] * me, rv = r[k] * mr;
-            if (rs.owned) atomicAdd(ge + k, dq * rv * me);
-            atomicAdd(gr + k, dq * ev * mr);
+            if (rs.owned) put(ge + k, dq * rv * me);
+            put(gr + k, dq * ev * mr);
         }
         return;
     }
@@ -286,11 +291,11 @@ __global__ __launch_bounds__(128) void prefix_backward_kernel(const float *__res
             dr1 = q1 * e1 + q2 * e2;  dr2 = q1 * e2 - q2 * e1;
         }
         if (rs.owned) {
-            atomicAdd(ge + k, de1 * me1);
-            atomicAdd(ge + h + k, de2 * me2);
+            put(ge + k, de1 * me1);
+            put(ge + h + k, de2 * me2);
         }
-        atomicAdd(gr + k, dr1 * mr1);
-        atomicAdd(gr + h + k, dr2 * mr2);
+        put(gr + k, dr1 * mr1);
+        put(gr + h + k, dr2 * mr2);
     }
 }
 
@@ -326,7 +331,8 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
                                                                   float *__restrict__ dE, float *__restrict__ dR,
                                                                   const double *__restrict__ loss_partials,
                                                                   int n_partials, double *__restrict__ loss_out,
-                                                                  float *__restrict__ dr_rows, float *__restrict__ de_rows)
+                                                                  float *__restrict__ dr_rows, float *__restrict__ de_rows,
+                                                                  int distinct)
 {
     // dr_rows / de_rows ([B][ldq] each, or nullptr): the relation- / entity-gradient row of every batch row is STORED there
     // instead of being added into dR / dE with float atomics -- row_segment_sum_kernel then adds up the rows of each
@@ -347,12 +353,14 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
     const size_t split_stride = (size_t)Bpad * ldq;
     const float *sl = slab + (size_t)b * ldq;
     const int s_lo = (nsplit * sq) >> 2, s_hi = (nsplit * (sq + 1)) >> 2;
+    // distinct (OKGE_TRAIN_DISTINCT_PREFIX_ROWS): every prefix id occurs once in the batch: the table's gradient row itself is
+    // a row of its own
     auto put_r = [&](float *pr, float4 v) {      // relation gradient: a row of its own (plain store) or an atomic add into dR
-        if (dr_rows) *reinterpret_cast<float4 *>(pr) = v;
+        if (dr_rows || distinct) *reinterpret_cast<float4 *>(pr) = v;
         else atomic_add4(pr, v);
     };
     auto put_e = [&](float *pe, float4 v) {
-        if (de_rows) *reinterpret_cast<float4 *>(pe) = v;
+        if (de_rows || distinct) *reinterpret_cast<float4 *>(pe) = v;
         else atomic_add4(pe, v);
     };
     auto dq_sum = [&](int k, bool active) {
@@ -994,7 +1002,8 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
                                   const float *slab, int nsplit, int Bpad, int ldq, const float *ent_rows, float *dE,
                                   float *dR, const double *loss_partials, int n_partials, double *loss_out,
                                   hipStream_t st, const int32_t *rel_order, const int32_t *rel_seg_ptr, int n_rel_seg,
-                                  const int32_t *ent_order, const int32_t *ent_seg_ptr, int n_ent_seg, float *grad_rows)
+                                  const int32_t *ent_order, const int32_t *ent_seg_ptr, int n_ent_seg, float *grad_rows,
+                                  int distinct)
 {
     const int B = p.n_po + p.n_sp;
     if (B <= 0) return hipSuccess;
@@ -1006,10 +1015,10 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
         float *dr_rows = seg_r ? grad_rows : nullptr, *de_rows = seg_e ? grad_rows + (size_t)Bpad * ldq : nullptr;
         if (nsplit >= 8)
             hipLaunchKernelGGL(prefix_backward_vec_kernel<8>, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
-                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows);
+                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct);
         else
             hipLaunchKernelGGL(prefix_backward_vec_kernel<1>, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
-                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows);
+                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct);
         if (seg_r || seg_e) {
             const RowSegments rel{rel_order, rel_seg_ptr, seg_r ? n_rel_seg : 0}, ent{ent_order, ent_seg_ptr, seg_e ? n_ent_seg : 0};
             hipLaunchKernelGGL(row_segment_sum_kernel, dim3(rel.n_seg + ent.n_seg), dim3(128), 0, st, dr_rows, de_rows, ldq, d, p,
@@ -1017,7 +1026,7 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
         }
     } else {
         hipLaunchKernelGGL(prefix_backward_kernel, dim3(B), dim3(128), 0, st, E, R, d, scorer, p, slab, nsplit, Bpad, ldq,
-                           ent_rows, dE, dR);
+                           ent_rows, dE, dR, distinct);
         if (loss_partials)
             hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_partials, n_partials, loss_out);
     }

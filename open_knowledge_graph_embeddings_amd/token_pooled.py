@@ -281,10 +281,10 @@ class TokenPooledTrainStep:
                            drop_po_rel=DS(H.STREAM_PO_REL), drop_sp_rel=DS(H.STREAM_SP_REL))
         self.engine.forward_backward(EVt[:N_c + B], RVt[:B], self.scorer, vb, dEV[:N_c + B], dRV[:B], loss=self.loss,
                                      label_smoothing=self.label_smoothing, normalizer=normalizer, loss_out=self.loss_out,
-                                     scores=scores, grads_zero=True)
+                                     scores=scores, grads_zero=True, distinct_prefix_rows=True)
+        # (every row of dEV / dRV is STORED by that call -- the candidate rows by the tile kernel (grads_zero), the prefix rows,
+        #  one per batch row in these virtual tables, by the prefix backward (distinct_prefix_rows): nothing to clear per step)
         pe.backward_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[6], c_[7]) for c_ in calls])
-        dEV[N_c:N_c + B].zero_()         # (the candidate rows are STORED by the next step's tile kernel: grads_zero)
-        dRV[:B].zero_()
         return self.loss_out
 
     def optimizer_step(self):

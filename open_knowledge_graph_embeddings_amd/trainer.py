@@ -49,9 +49,10 @@ class _VirtualTablesLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, EV, RV, engine, scorer, vb, kind, smoothing, scores):
         EVc, RVc = EV.detach().contiguous(), RV.detach().contiguous()
-        dEV, dRV = torch.zeros_like(EVc), torch.zeros_like(RVc)
+        # every row of the two virtual tables is one candidate or one batch row: all of them are STORED by the call
+        dEV, dRV = torch.empty_like(EVc), torch.empty_like(RVc)
         loss = engine.forward_backward(EVc, RVc, scorer, vb, dEV, dRV, loss=kind, label_smoothing=smoothing, normalizer=1.0,
-                                       scores=scores, grads_zero=True)
+                                       scores=scores, grads_zero=True, distinct_prefix_rows=True)
         ctx.engine, ctx.grads = engine, (dEV, dRV)
         return loss.to(torch.float32).reshape(())               # (the cast already yields a fresh tensor)
 

@@ -176,8 +176,9 @@ class OracleShardEngine:
         return loss_out
 
     def forward_backward(self, E, R, scorer, batch, dE, dR, loss="bce", label_smoothing=0.0, normalizer=None,
-                         loss_out=None, scores=None, grads_zero=False, loss_only=False):
-        """the whole fused call (replica mode): oracle step on this rank's batch"""
+                         loss_out=None, scores=None, grads_zero=False, loss_only=False, distinct_prefix_rows=False):
+        """the whole fused call (replica mode): oracle step on this rank's batch (gradients are ADDED: the callers here
+        clear their buffers, so the store-instead-of-accumulate flags change nothing)"""
         En, Rn = _np(E), _np(R)
         d = En.shape[1]
         cand = _np(batch.cand_ids) if batch.cand_ids is not None else np.arange(batch.cand_first, batch.cand_first + batch.n_cand)
