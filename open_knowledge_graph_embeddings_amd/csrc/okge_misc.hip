@@ -531,6 +531,12 @@ __global__ __launch_bounds__(256) void kl_row_lse_kernel(const float *__restrict
     }
 }
 
+__device__ __forceinline__ bool bits_differ(const float4 &a, const float4 &b)
+{
+    return ((__float_as_uint(a.x) ^ __float_as_uint(b.x)) | (__float_as_uint(a.y) ^ __float_as_uint(b.y)) |
+            (__float_as_uint(a.z) ^ __float_as_uint(b.z)) | (__float_as_uint(a.w) ^ __float_as_uint(b.w))) != 0u;
+}
+
 __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, float *__restrict__ g,
                                                       float *__restrict__ sum, int64_t n, float lr, float wd,
                                                       float eps, int zero_grad)
@@ -540,6 +546,7 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, flo
     float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g), *s4 = reinterpret_cast<float4 *>(sum);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pv = p4[i], gv = g4[i], sv = s4[i];
+        const float4 p_old = pv, s_old = sv;
         float *pp = &pv.x, *gg = &gv.x, *ss = &sv.x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -547,8 +554,13 @@ __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, flo
             ss[j] = fmaf(gj, gj, ss[j]);
             pp[j] = pp[j] - lr * (gj / (sqrtf(ss[j]) + eps));
         }
-        p4[i] = pv;
-        s4[i] = sv;
+        // store only what changed.  A row no gradient reached still moves by the weight-decay term (the reference applies
+        // wd = 1e-10 to ALL rows, utils/optim.py:139-160) -- but once its accumulator has seen a real gradient, that term is
+        // below half an ulp of both the accumulator and the parameter and the arithmetic above returns the old bits: such
+        // rows (most token rows of a token-pooled step, the entities outside a sampled candidate list) then cost three
+        // read streams instead of three reads + two writes.  Memory ends up bit-identical to the unconditional stores.
+        if (bits_differ(pv, p_old)) p4[i] = pv;
+        if (bits_differ(sv, s_old)) s4[i] = sv;
         // (clear only what is not clear already: rows no gradient reached -- most token rows of a token-pooled step, the
         //  entities outside a sampled candidate list -- cost one store stream less: a sixth of this HBM-bound sweep)
         if (zero_grad && ((__float_as_uint(gv.x) | __float_as_uint(gv.y) | __float_as_uint(gv.z) | __float_as_uint(gv.w)) != 0u))
@@ -603,6 +615,7 @@ __device__ __forceinline__ void adagrad_sweep(const AdagradSeg sg, float lr, flo
     float4 *p4 = reinterpret_cast<float4 *>(sg.p), *g4 = reinterpret_cast<float4 *>(sg.g), *s4 = reinterpret_cast<float4 *>(sg.s);
     for (int64_t i = first; i < n4; i += stride) {
         float4 pv = p4[i], gv = g4[i], sv = s4[i];
+        const float4 p_old = pv, s_old = sv;
         float *pp = &pv.x, *gg = &gv.x, *ss = &sv.x;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -610,8 +623,13 @@ __device__ __forceinline__ void adagrad_sweep(const AdagradSeg sg, float lr, flo
             ss[j] = fmaf(gj, gj, ss[j]);
             pp[j] = pp[j] - lr * (gj / (sqrtf(ss[j]) + eps));
         }
-        p4[i] = pv;
-        s4[i] = sv;
+        // store only what changed.  A row no gradient reached still moves by the weight-decay term (the reference applies
+        // wd = 1e-10 to ALL rows, utils/optim.py:139-160) -- but once its accumulator has seen a real gradient, that term is
+        // below half an ulp of both the accumulator and the parameter and the arithmetic above returns the old bits: such
+        // rows (most token rows of a token-pooled step, the entities outside a sampled candidate list) then cost three
+        // read streams instead of three reads + two writes.  Memory ends up bit-identical to the unconditional stores.
+        if (bits_differ(pv, p_old)) p4[i] = pv;
+        if (bits_differ(sv, s_old)) s4[i] = sv;
         // (clear only what is not clear already: rows no gradient reached -- most token rows of a token-pooled step, the
         //  entities outside a sampled candidate list -- cost one store stream less: a sixth of this HBM-bound sweep)
         if (zero_grad && ((__float_as_uint(gv.x) | __float_as_uint(gv.y) | __float_as_uint(gv.z) | __float_as_uint(gv.w)) != 0u))
