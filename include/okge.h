@@ -145,6 +145,12 @@ int okge_score_prefixes(const okge_tables *t, const okge_prefix_batch *batch, co
  *               token-pooled embedder and the embedder variants score: row = position, model.py:762-786 / :463-479):
  *               their gradient rows are STORED, not accumulated -- no float atomics, and the caller need not clear them. */
 #define OKGE_TRAIN_DISTINCT_PREFIX_ROWS 8
+/*               OKGE_TRAIN_CLEAR_GRADS -- dE and dR may hold anything on entry: the call stores the candidate rows of dE (as
+ *               with OKGE_TRAIN_GRADS_ZERO) and itself clears what it only accumulates into -- all of dR, the rows of dE
+ *               outside the candidate range -- inside its first launch.  What zero_grad + a fresh .grad buffer are in the
+ *               reference (trainer.py:229-234) without two fill launches per step.  Contiguous candidate range
+ *               (cand->ids == NULL), unsharded table. */
+#define OKGE_TRAIN_CLEAR_GRADS 16
 int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *batch,
                                 const okge_candidates *cand, const okge_positives *pos,
                                 int32_t loss_kind, float label_smoothing, double normalizer, int32_t flags,

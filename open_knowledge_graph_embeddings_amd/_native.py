@@ -24,6 +24,7 @@ OKGE_TRAIN_GRADS_ZERO = 1
 OKGE_TRAIN_LOSS_ONLY = 2
 OKGE_TRAIN_UNIQUE_CANDIDATES = 4
 OKGE_TRAIN_DISTINCT_PREFIX_ROWS = 8
+OKGE_TRAIN_CLEAR_GRADS = 16
 SCORERS = {"complex": OKGE_COMPLEX, "distmult": OKGE_DISTMULT}
 LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 

@@ -505,6 +505,11 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     make_geometry(B, cand->n, t->d, g);
     if (!workspace || workspace_bytes < g.total) return fail(OKGE_ERR_WORKSPACE, "workspace too small");
     if (q_ext && ldq_ext != g.ldq) return fail(OKGE_ERR_INVALID, "query block leading dimension must be okge_query_ld(d)");
+    const bool clear_grads = (flags & OKGE_TRAIN_CLEAR_GRADS) != 0 && !loss_only;
+    if (clear_grads) {
+        if (cand->ids || sh || !dR) return fail(OKGE_ERR_INVALID, "OKGE_TRAIN_CLEAR_GRADS needs a contiguous candidate range on an unsharded table");
+        flags |= OKGE_TRAIN_GRADS_ZERO;          // the candidate rows are stored, everything else is cleared below
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
     const int cand_col0 = sh ? sh->cand_col0 : 0;
@@ -515,9 +520,17 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         PrefixDev p;
         std::memset(&p, 0, sizeof(p));
         if (!q_ext) p = to_dev(*batch, t, sh);
+        ClearSpec clr = {};
+        if (clear_grads) {                        // all of dR; the rows of dE in front of and behind the candidate range
+            const int64_t d64 = t->d, hi = (int64_t)cand->first_id + cand->n;
+            clr.p[0] = dR;                      clr.n[0] = (int64_t)t->n_rel * d64;
+            clr.p[1] = dE;                      clr.n[1] = (int64_t)cand->first_id * d64;
+            clr.p[2] = dE + hi * d64;           clr.n[2] = ((int64_t)t->n_ent - hi) * d64;
+        }
         e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
                                   q_ext ? 0 : g.Bpad, nullptr, pos->col, pos->nnz,
-                                  reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles, g.tile_w, cand_col0, st);
+                                  reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles, g.tile_w, cand_col0, st,
+                                  clear_grads ? &clr : nullptr);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;

@@ -97,9 +97,11 @@ hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, 
 hipError_t launch_fused64(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);   // slot sizes above 256
 
+// up to three float regions cleared by extra workgroups of encode_queries_kernel (OKGE_TRAIN_CLEAR_GRADS)
+struct ClearSpec { float *p[3]; int64_t n[3]; };
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
-                                 int tiles, int tile_w, int cand_col0, hipStream_t st);
+                                 int tiles, int tile_w, int cand_col0, hipStream_t st, const ClearSpec *clear = nullptr);
 hipError_t launch_fold_queries(const float *R, int d, int scorer, const PrefixDev &p, const float *ent_rows, float *Q, int ldq,
                                int Bpad, hipStream_t st);
 hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, const double *loss_partials,

@@ -79,8 +79,26 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
                                                              float *__restrict__ ent_rows,
                                                              const int32_t *__restrict__ pos_col, int nnz,
                                                              int32_t *__restrict__ tile_ptr, int tiles, int tile_w,
-                                                             int cand_col0)
+                                                             int cand_col0, int tp_wgs, const ClearSpec clr)
 {
+    if ((int)blockIdx.x >= Bpad + tp_wgs) {
+        // more extra workgroups (OKGE_TRAIN_CLEAR_GRADS): the gradient regions the step accumulates into without storing
+        // them first -- all of dR, the rows of dE outside the candidate range -- are cleared here, one float4 per thread, in
+        // the launch that precedes every kernel that adds to them (instead of two fill launches by the caller)
+        int64_t i = 4 * (((int64_t)blockIdx.x - Bpad - tp_wgs) * 128 + threadIdx.x);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float *base = clr.p[r];
+            const int64_t n = clr.n[r], n4 = (n + 3) / 4 * 4;
+            if (i < n4) {
+                if (i + 4 <= n && (reinterpret_cast<uintptr_t>(base + i) & 15) == 0) *reinterpret_cast<float4 *>(base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else for (int64_t j = i; j < n && j < i + 4; ++j) base[j] = 0.f;
+                return;
+            }
+            i -= n4;
+        }
+        return;
+    }
     if ((int)blockIdx.x >= Bpad) {
         // extra workgroups: offsets of each candidate tile's positives in the column-sorted coordinate list
         const int t = ((int)blockIdx.x - Bpad) * 128 + threadIdx.x;
@@ -967,12 +985,21 @@ hipError_t launch_score_triples(const float *S, int64_t lds_, const float *Rr, i
 
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
-                                 int tiles, int tile_w, int cand_col0, hipStream_t st)
+                                 int tiles, int tile_w, int cand_col0, hipStream_t st, const ClearSpec *clear)
 {
     const int extra = tile_ptr ? (tiles + 1 + 127) / 128 : 0;
-    if (Bpad + extra <= 0) return hipSuccess;
-    hipLaunchKernelGGL(encode_queries_kernel, dim3(Bpad + extra), dim3(128), 0, st, E, R, d, scorer, p, Q, ldq, Bpad,
-                       ent_rows, pos_col, nnz, tile_ptr, tiles, tile_w, cand_col0);
+    ClearSpec clr = {};
+    int64_t clear_wgs = 0;
+    if (clear) {
+        clr = *clear;
+        int64_t f4 = 0;
+        for (int r = 0; r < 3; ++r) f4 += clr.p[r] ? (clr.n[r] + 3) / 4 : 0;
+        for (int r = 0; r < 3; ++r) if (!clr.p[r]) clr.n[r] = 0;
+        clear_wgs = (f4 + 127) / 128;
+    }
+    if (Bpad + extra + clear_wgs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(encode_queries_kernel, dim3((unsigned)(Bpad + extra + clear_wgs)), dim3(128), 0, st, E, R, d, scorer, p, Q,
+                       ldq, Bpad, ent_rows, pos_col, nnz, tile_ptr, tiles, tile_w, cand_col0, extra, clr);
     return hipGetLastError();
 }
 

@@ -234,9 +234,9 @@ class HotPath:
 
     def forward_backward(self, E, R, scorer, batch: PrefixBatch, dE, dR, loss="bce", label_smoothing=0.0,
                          normalizer=None, loss_out=None, scores=None, grads_zero=False, loss_only=False,
-                         distinct_prefix_rows=False):
-        """Fused forward + loss + backward; accumulates into dE / dR; returns the summed loss as a
-        device double[1] tensor (no host sync)."""
+                         distinct_prefix_rows=False, clear_grads=False):
+        """Fused forward + loss + backward; accumulates into dE / dR (clear_grads: into whatever-they-held buffers that the
+        call itself clears, okge.h OKGE_TRAIN_CLEAR_GRADS); returns the summed loss as a device double[1] tensor (no host sync)."""
         self._check(batch, E, R)
         pb, c, keep = self._batch(batch)
         t = self._tables(E, R, scorer)
@@ -254,7 +254,8 @@ class HotPath:
             N.LOSSES[loss] if isinstance(loss, str) else int(loss), float(label_smoothing), float(normalizer),
             (N.OKGE_TRAIN_GRADS_ZERO if grads_zero else 0) | (N.OKGE_TRAIN_LOSS_ONLY if loss_only else 0) |
             (N.OKGE_TRAIN_UNIQUE_CANDIDATES if batch.cand_unique else 0) |
-            (N.OKGE_TRAIN_DISTINCT_PREFIX_ROWS if distinct_prefix_rows else 0),
+            (N.OKGE_TRAIN_DISTINCT_PREFIX_ROWS if distinct_prefix_rows else 0) |
+            (N.OKGE_TRAIN_CLEAR_GRADS if clear_grads else 0),
             loss_out.data_ptr(), _ptr(dE), _ptr(dR),
             None if scores is None else scores.data_ptr(), 0 if scores is None else scores.stride(0),
             ws.data_ptr(), self._ws_bytes, self._stream()), "okge_train_forward_backward")

@@ -164,22 +164,20 @@ class AddLossModule(nn.Module):
         batch.drop_po_ent, batch.drop_sp_ent = m.dropout_spec(H.STREAM_PO_ENT), m.dropout_spec(H.STREAM_SP_ENT)
         batch.drop_po_rel, batch.drop_sp_rel = m.dropout_spec(H.STREAM_PO_REL, True), m.dropout_spec(H.STREAM_SP_REL, True)
         if want_grad:
-            if batch.cand_ids is None and batch.cand_first + n == m.E.shape[0]:
-                # 1-vs-all: the tile kernel STORES every candidate row's gradient (grads_zero), so only the reserved rows
-                # in front of the candidates need clearing -- not an 11.6 MB memset per step
-                g_e = torch.empty_like(m.E)
-                g_e[:batch.cand_first].zero_()
-            else:
-                g_e = torch.zeros_like(m.E)
-            g_r = torch.zeros_like(m.R)
+            E, R = m.E, m.R
+            # a contiguous candidate range: the call stores the candidate rows and clears the rest itself (all of dR, the
+            # reserved rows in front of the candidates) inside its first launch -- fresh buffers, no fill launches.
+            # An id list: candidate rows accumulate, so the buffers start from zero.
+            clear = batch.cand_ids is None
+            g_e, g_r = (torch.empty_like(E), torch.empty_like(R)) if clear else (torch.zeros_like(E), torch.zeros_like(R))
             # the factor the Trainer will apply (trainer.py:221: loss / normalizer_loss, normalizer_loss = B x N,
             # dataset.py:935) goes into the fused step; _FusedLossFn.backward checks it against what autograd delivers
             # (torch divides a fp32 tensor by a Python number as a multiplication by fp32(1) / fp32(number), forward and
             #  backward: `applied` is built the same way, and the normalizer handed to the library is the one whose fp32
             #  reciprocal is exactly that)
             applied = np.float32(1.0) / np.float32(float(B) * float(n))
-            loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, g_e, g_r, loss=kind, label_smoothing=smoothing,
-                                        normalizer=1.0 / float(applied), scores=all_outputs, grads_zero=True)
+            loss = eng.forward_backward(E, R, m.scorer_name, batch, g_e, g_r, loss=kind, label_smoothing=smoothing,
+                                        normalizer=1.0 / float(applied), scores=all_outputs, grads_zero=True, clear_grads=clear)
             result = _FusedLossFn.apply(m.entity_embedding.weight, m.relation_embedding.weight, loss, g_e, g_r, eng,
                                         float(applied))
         else:
