@@ -294,6 +294,41 @@ def test_repeated_candidate_ids_accumulate(hp, grads_zero):
     np.testing.assert_allclose(dE2.cpu().numpy(), ref2["dE"], rtol=0, atol=3e-5 * np.abs(ref2["dE"]).max())
 
 
+@pytest.mark.parametrize("scorer,d,lo,hi", [("complex", 200, 2, 300), ("distmult", 37, 17, 251), ("complex", 64, 0, 129)])
+def test_clear_grads_flag(hp, scorer, d, lo, hi):
+    """OKGE_TRAIN_CLEAR_GRADS: gradient buffers full of garbage, a contiguous candidate range anywhere in the table -- the
+    call stores the candidate rows and clears everything else it accumulates into (all of dR, the rows of dE in front of and
+    behind the candidates) inside its first launch: the same gradients as zeroed buffers + OKGE_TRAIN_GRADS_ZERO, exact
+    zeros where nothing was added, and equal to the oracle.  An id list is refused."""
+    from open_knowledge_graph_embeddings_amd._native import OkgeError
+    n_ent, n_rel = 300, 9
+    E, R, z, _, _ = random_problem(d + lo, n_ent, n_rel, d, 40, 33)
+    rng = np.random.default_rng(hi)
+    cand = np.arange(lo, hi).astype(np.int32)
+    y = np.zeros((73, len(cand)), np.float32)
+    for b in range(73):
+        y[b, rng.choice(len(cand), size=3, replace=False)] = 1
+    ref = oracle_step(scorer, E, R, z, cand, y)
+    Et, Rt = dev(E), dev(R)
+    batch = make_batch(z, cand, None, labels=y)
+    batch.cand_ids, batch.cand_first, batch.n_cand = None, lo, hi - lo
+    dE0, dR0 = torch.zeros_like(Et), torch.zeros_like(Rt)
+    loss0 = hp.forward_backward(Et, Rt, scorer, batch, dE0, dR0, grads_zero=True).clone()
+    dE1, dR1 = torch.full_like(Et, float("nan")), torch.full_like(Rt, 123.0)
+    loss1 = hp.forward_backward(Et, Rt, scorer, batch, dE1, dR1, clear_grads=True)
+    assert float(loss0) == float(loss1)
+    # (not bit for bit: the prefix rows and the relation rows are float atomics in either call; a NaN left behind would show)
+    for a0, a1 in ((dE0, dE1), (dR0, dR1)):
+        np.testing.assert_allclose(a1.cpu().numpy(), a0.cpu().numpy(), rtol=0, atol=2e-6 * float(a0.abs().max()))
+    untouched = np.setdiff1d(np.arange(n_ent), np.concatenate([cand, z["po_obj"], z["sp_subj"]]))
+    assert float(dE1[torch.from_numpy(untouched).cuda()].abs().max()) == 0.0 if len(untouched) else True
+    for mine, r in ((dE1, ref["dE"]), (dR1, ref["dR"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=3e-5 * np.abs(r).max() + 1e-12)
+    listed = make_batch(z, cand, None, labels=y)
+    with pytest.raises(OkgeError):
+        hp.forward_backward(Et, Rt, scorer, listed, dE1, dR1, clear_grads=True)
+
+
 def test_b_split_path(hp, monkeypatch):
     """Few candidate tiles -> the batch is split across blockIdx.y; partial dC rows go to slabs summed by dc_reduce."""
     E, R, z, cand, y = random_problem(5, 300, 11, 64, 200, 184, 100)
