@@ -396,7 +396,8 @@ FusedArgs range_args(const FusedArgs &base, const Geometry &g, int r, int &tiles
 
 // per-row log-sum-exp over all candidates of the call (KL loss): one score-statistics pass per candidate range, merged
 // into a running (max, sum-exp) per row; the (B, N) scores are never materialised
-int lse_pass(const Geometry &g, const FusedArgs &base, char *ws, float *row_lse, hipStream_t st)
+int lse_pass(const Geometry &g, const FusedArgs &base, char *ws, float *row_lse, hipStream_t st,
+             const int32_t *count_pos_row = nullptr, int count_nnz = 0, float *count_ysum = nullptr)
 {
     FusedArgs b = base;
     b.stats = reinterpret_cast<float *>(ws + g.off_stats);
@@ -415,7 +416,8 @@ int lse_pass(const Geometry &g, const FusedArgs &base, char *ws, float *row_lse,
         ScopedTimer tm("kl_row_lse", st);
         // the 64x64 cut emits one (max, sum-exp) per 64-candidate tile, the 32x32 cut one per 16-candidate block
         e = launch_kl_row_lse(s.stats, g.KB <= 16 ? tiles_r : 4 * tiles_r, g.B, g.Bpad,
-                              reinterpret_cast<float *>(ws + g.off_run), r == 0, r == g.n_ranges - 1, row_lse, st);
+                              reinterpret_cast<float *>(ws + g.off_run), r == 0, r == g.n_ranges - 1, row_lse, st,
+                              r == 0 ? count_pos_row : nullptr, count_nnz, r == 0 ? count_ysum : nullptr);   // + the rows' label mass
         if (e != hipSuccess) return fail_hip(e, "kl_row_lse");
     }
     return OKGE_OK;
@@ -521,6 +523,8 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         std::memset(&p, 0, sizeof(p));
         if (!q_ext) p = to_dev(*batch, t, sh);
         ClearSpec clr = {};
+        const bool kl_own_lse = loss_kind == OKGE_LOSS_KL && !row_lse_ext && !sh;
+        if (kl_own_lse) { clr.p[3] = reinterpret_cast<float *>(ws + g.off_ysum); clr.n[3] = g.Bpad; }   // counted in lse_pass
         if (clear_grads) {                        // all of dR; the rows of dE in front of and behind the candidate range
             const int64_t d64 = t->d, hi = (int64_t)cand->first_id + cand->n;
             clr.p[0] = dR;                      clr.n[0] = (int64_t)t->n_rel * d64;
@@ -530,7 +534,7 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
                                   q_ext ? 0 : g.Bpad, nullptr, pos->col, pos->nnz,
                                   reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles, g.tile_w, cand_col0, st,
-                                  clear_grads ? &clr : nullptr);
+                                  (clear_grads || kl_own_lse) ? &clr : nullptr);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
@@ -570,11 +574,17 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     if (loss_kind == OKGE_LOSS_KL) {
         if (sh && !row_lse_ext)
             return fail(OKGE_ERR_INVALID, "sharded KL loss: pass the all-shard row log-sum-exp (okge_row_logsumexp + exchange)");
-        if (!row_lse_ext)
-            if (int rc = lse_pass(g, a, ws, reinterpret_cast<float *>(ws + g.off_lse), st)) return rc;
-        ScopedTimer tm("kl_count_pos", st);       // label mass per row (trainer.py:99-101: y is not normalised)
-        e = launch_kl_count_pos(pos->row, pos->nnz, g.Bpad, reinterpret_cast<float *>(ws + g.off_ysum), st);
-        if (e != hipSuccess) return fail_hip(e, "kl_count_pos");
+        if (!row_lse_ext) {
+            // (the label mass per row, trainer.py:99-101, is counted by extra workgroups of the pass' first kl_row_lse launch;
+            //  its buffer was cleared by the encode launch above)
+            if (int rc = lse_pass(g, a, ws, reinterpret_cast<float *>(ws + g.off_lse), st, pos->row, pos->nnz,
+                                  reinterpret_cast<float *>(ws + g.off_ysum)))
+                return rc;
+        } else {
+            ScopedTimer tm("kl_count_pos", st);   // label mass per row (trainer.py:99-101: y is not normalised)
+            e = launch_kl_count_pos(pos->row, pos->nnz, g.Bpad, reinterpret_cast<float *>(ws + g.off_ysum), st);
+            if (e != hipSuccess) return fail_hip(e, "kl_count_pos");
+        }
         a.row_lse = row_lse_ext ? row_lse_ext : reinterpret_cast<const float *>(ws + g.off_lse);
         a.row_ysum = reinterpret_cast<const float *>(ws + g.off_ysum);
     }

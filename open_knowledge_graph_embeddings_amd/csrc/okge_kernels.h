@@ -97,8 +97,10 @@ hipError_t launch_fused32(int mode, const FusedArgs &a, int grid_x, int grid_y, 
 hipError_t launch_fused64(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);
 hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y, hipStream_t st);   // slot sizes above 256
 
-// up to three float regions cleared by extra workgroups of encode_queries_kernel (OKGE_TRAIN_CLEAR_GRADS)
-struct ClearSpec { float *p[3]; int64_t n[3]; };
+// up to four float regions cleared by extra workgroups of encode_queries_kernel (OKGE_TRAIN_CLEAR_GRADS: dR, dE in front of
+// and behind the candidates; the KL loss' per-row label mass before it is counted)
+constexpr int CLEAR_REGIONS = 4;
+struct ClearSpec { float *p[CLEAR_REGIONS]; int64_t n[CLEAR_REGIONS]; };
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
                                  int tiles, int tile_w, int cand_col0, hipStream_t st, const ClearSpec *clear = nullptr);
@@ -115,7 +117,7 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
 hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
 hipError_t launch_kl_count_pos(const int32_t *pos_row, int nnz, int Bpad, float *row_ysum, hipStream_t st);
 hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, float *run, int first, int last, float *row_lse,
-                             hipStream_t st);
+                             hipStream_t st, const int32_t *pos_row = nullptr, int nnz = 0, float *row_ysum = nullptr);
 hipError_t launch_encode_rows(const float *table, int64_t table_rows, int d, const int32_t *ids, int first_id, int n,
                               const DropDev &drop, float *out, int64_t ld_out, int *id_err, hipStream_t st);
 hipError_t launch_scale(float *x, int64_t n, const float *alpha_dev, hipStream_t st);

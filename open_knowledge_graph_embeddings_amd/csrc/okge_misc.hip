@@ -87,7 +87,7 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
         // the launch that precedes every kernel that adds to them (instead of two fill launches by the caller)
         int64_t i = 4 * (((int64_t)blockIdx.x - Bpad - tp_wgs) * 128 + threadIdx.x);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < CLEAR_REGIONS; ++r) {
             float *base = clr.p[r];
             const int64_t n = clr.n[r], n4 = (n + 3) / 4 * 4;
             if (i < n4) {
@@ -522,8 +522,17 @@ __global__ __launch_bounds__(256) void kl_count_pos_kernel(const int32_t *__rest
 // over the tiles (a thread per row walked 2 x tiles strided loads in sequence: 98 us at 228 tiles)
 __global__ __launch_bounds__(256) void kl_row_lse_kernel(const float *__restrict__ stats, int tiles, int B, int Bpad,
                                                          float2 *__restrict__ run, int first, int last,
-                                                         float *__restrict__ row_lse)
+                                                         float *__restrict__ row_lse, int row_blocks,
+                                                         const int32_t *__restrict__ pos_row, int nnz,
+                                                         float *__restrict__ row_ysum)
 {
+    if ((int)blockIdx.x >= row_blocks) {
+        // extra workgroups: label mass per row (trainer.py:99-101: y is not normalised) -- row_ysum was cleared by the step's
+        // first launch; this replaces a memset + a launch of its own
+        const int i = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        if (i < nnz && pos_row[i] >= 0) atomicAdd(row_ysum + pos_row[i], 1.0f);      // row < 0: padding (fixed-size graphs)
+        return;
+    }
     // candidate ranges: `run` carries the row's (max, sum of exp(x - max)) over the ranges seen so far
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (b >= B) return;
@@ -993,8 +1002,8 @@ hipError_t launch_encode_queries(const float *E, const float *R, int d, int scor
     if (clear) {
         clr = *clear;
         int64_t f4 = 0;
-        for (int r = 0; r < 3; ++r) f4 += clr.p[r] ? (clr.n[r] + 3) / 4 : 0;
-        for (int r = 0; r < 3; ++r) if (!clr.p[r]) clr.n[r] = 0;
+        for (int r = 0; r < CLEAR_REGIONS; ++r) f4 += clr.p[r] ? (clr.n[r] + 3) / 4 : 0;
+        for (int r = 0; r < CLEAR_REGIONS; ++r) if (!clr.p[r]) clr.n[r] = 0;
         clear_wgs = (f4 + 127) / 128;
     }
     if (Bpad + extra + clear_wgs <= 0) return hipSuccess;
@@ -1093,11 +1102,12 @@ hipError_t launch_kl_count_pos(const int32_t *pos_row, int nnz, int Bpad, float 
 }
 
 hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, float *run, int first, int last, float *row_lse,
-                             hipStream_t st)
+                             hipStream_t st, const int32_t *pos_row, int nnz, float *row_ysum)
 {
     if (tiles <= 0 || B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kl_row_lse_kernel, dim3((B + 3) / 4), dim3(256), 0, st, stats, tiles, B, Bpad,
-                       reinterpret_cast<float2 *>(run), first, last, row_lse);
+    const int row_blocks = (B + 3) / 4, count_blocks = (row_ysum && nnz > 0) ? (nnz + 255) / 256 : 0;
+    hipLaunchKernelGGL(kl_row_lse_kernel, dim3(row_blocks + count_blocks), dim3(256), 0, st, stats, tiles, B, Bpad,
+                       reinterpret_cast<float2 *>(run), first, last, row_lse, row_blocks, pos_row, nnz, row_ysum);
     return hipGetLastError();
 }
 
