@@ -15,6 +15,9 @@ from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
 import bench
 
 w = synthetic.WORKLOADS["S-FB"]
+if os.environ.get("OKGE_TL_D"):                      # another slot size at the S-FB shape (e.g. 256: the single-buffer instance)
+    import dataclasses
+    w = dataclasses.replace(w, d=int(os.environ["OKGE_TL_D"]))
 dev = torch.device("cuda:0")
 E, R = synthetic.make_tables(w)
 step = FusedTrainStep(torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev), w.scorer, lr=w.lr,
