@@ -90,6 +90,61 @@ def test_random_shape(okge_lib, monkeypatch, i):
         np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=5e-5 * np.abs(r).max() + 5e-7, err_msg=str(info))   # + exp/log noise where the true gradient is 0 (600 further seeds pass)
 
 
+@pytest.mark.parametrize("i", range(8))
+def test_random_shape_more_tiles_than_cus(okge_lib, monkeypatch, i):
+    """the same sweep where the candidate tiles outnumber the CUs (N 16.5 k .. 40 k, B 192 .. 700): rounds of one workgroup
+    per CU, the leftover tiles launched apart with the rows split across workgroups (okge_api.hip tail_split), candidate
+    ranges of whole rounds when the G^T budget is forced small -- against the oracle, both losses, dropout, id lists"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    rng = np.random.default_rng(8100 + i)
+    scorer = "complex" if i % 2 == 0 else "distmult"
+    d = int(rng.choice([8, 64, 130, 200, 256]))
+    N = int(rng.integers(16500, 40000))
+    n_ent, n_rel = N + 2 + int(rng.integers(0, 300)), int(rng.integers(5, 40))
+    n_po, n_sp = int(rng.integers(90, 360)), int(rng.integers(100, 340))
+    B = n_po + n_sp
+    cand = np.arange(2, 2 + N) if i % 3 else (2 + rng.permutation(n_ent - 2)[:N])
+    loss = "kl" if i % 4 == 1 else "bce"
+    smoothing = 0.1 if i % 4 == 2 else 0.0
+    p = float(rng.choice([0.0, 0.3]))
+    E = (rng.standard_normal((n_ent, d)) * 0.4).astype(np.float32)
+    R = (rng.standard_normal((n_rel, d)) * 0.4).astype(np.float32)
+    z = dict(po_rel=rng.integers(2, n_rel, n_po).astype(np.int32), po_obj=rng.integers(2, n_ent, n_po).astype(np.int32),
+             sp_subj=rng.integers(2, n_ent, n_sp).astype(np.int32), sp_rel=rng.integers(2, n_rel, n_sp).astype(np.int32))
+    y = np.zeros((B, N), np.float32)
+    for b in range(B):
+        y[b, rng.choice(N, size=int(rng.integers(0, 4)), replace=False)] = 1
+    y[0, N - 1] = y[B - 1, N - 1] = y[B // 2, 64 * (N // 64 // 256 * 256)] = 1           # positives inside the tail tiles
+    seed, step = 0x5EED0000 + i, 11 + i
+    kw = {}
+    if p > 0:
+        kw = dict(p_ent=p, keep_cand=ko.dropout_keep_mask(seed, H.STREAM_CAND, step, N, d, p),
+                  keep_po_ent=ko.dropout_keep_mask(seed, H.STREAM_PO_ENT, step, n_po, d, p),
+                  keep_sp_ent=ko.dropout_keep_mask(seed, H.STREAM_SP_ENT, step, n_sp, d, p))
+    ref = oracle_step(scorer, E, R, z, cand.astype(np.int32), y, loss, smoothing, **kw)
+    batch = make_batch(z, cand.astype(np.int32), None, labels=y)
+    if i % 3:
+        batch.cand_ids, batch.cand_first, batch.n_cand = None, 2, N
+    else:
+        batch.cand_unique = bool(i % 2)
+    if p > 0:
+        batch.drop_cand = H.DropoutSpec(p, seed, H.STREAM_CAND, step)
+        batch.drop_po_ent = H.DropoutSpec(p, seed, H.STREAM_PO_ENT, step)
+        batch.drop_sp_ent = H.DropoutSpec(p, seed, H.STREAM_SP_ENT, step)
+    if i % 4 == 3:
+        monkeypatch.setenv("OKGE_GT_MBYTES", str(max(1, ((B + 63) // 64 * 64) * 64 * 4 * 256 // (1 << 20))))   # ranges of one round
+    hp = H.HotPath("cuda:0")
+    hp._ws, hp._ws_bytes = None, 0
+    Et, Rt = dev(E), dev(R)
+    dE, dR = torch.zeros_like(Et), torch.zeros_like(Rt)
+    lossv = hp.forward_backward(Et, Rt, scorer, batch, dE, dR, loss=loss, label_smoothing=smoothing, grads_zero=bool(i % 2))
+    torch.cuda.synchronize()
+    info = dict(i=i, scorer=scorer, d=d, N=N, B=B, loss=loss, p=p)
+    assert abs(lossv.item() - ref["loss"]) <= 5e-5 * abs(ref["loss"]) + 1e-5, (info, lossv.item(), ref["loss"])
+    for mine, r in ((dE, ref["dE"]), (dR, ref["dR"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), r, rtol=0, atol=5e-5 * np.abs(r).max() + 5e-7, err_msg=str(info))
+
+
 @pytest.mark.parametrize("i", range(24))
 def test_random_ranks(okge_lib, i):
     """filtered ranks on random score matrices with forced ties, multi-mention groups, many groups per row, long filter
