@@ -276,11 +276,26 @@ typedef struct okge_pool_call {
     float *saved;
     const float *d_out;
     float *dW, *d_bn_weight, *d_bn_bias;
+    uint8_t *row_touched;        /* backward, optional: [vocab] bytes; row_touched[t] = touched_stamp for every row t of dW written */
+    int32_t touched_stamp;       /* 1..255 (okge_adagrad_multi reads the map with the same stamp) */
+    int32_t _pad;
 } okge_pool_call;
 int okge_pool_encode_calls(const okge_pool_call *calls, int32_t n_calls, int32_t training, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* Backward of a batch of calls.  The scatter-add into the token tables' dense gradients
+ * (torch.nn.Embedding's backward under model.py:762-771) runs
+ *   scatter_state == NULL: with float atomics (any pooling; the sums depend on arrival order in the last bits);
+ *   scatter_state != NULL: store-and-sum through an inverted index the kernels build from the batch's token ids -- every
+ *     gradient row is added up by one owner in ascending (row, position) order: BIT-REPRODUCIBLE, and ~2x the speed at
+ *     BASELINE configs[4].  Needs sum / mean pooling and slot sizes that are a multiple of 4 (else OKGE_ERR_UNSUPPORTED).
+ *     scatter_state: okge_pool_scatter_state_bytes(calls) bytes that the caller zeroes ONCE and thereafter only hands to
+ *     this function (it leaves them zero; one call at a time per buffer); workspace: okge_pool_backward_workspace_bytes.
+ * row_touched / touched_stamp (optional, both paths): a byte per table row for okge_adagrad_multi, so the optimizer
+ * sweep skips the gradient rows no token of the batch named. */
 int okge_pool_backward_calls(const okge_pool_call *calls, int32_t n_calls, void *workspace, size_t workspace_bytes,
-                             void *stream);
+                             void *scatter_state, size_t scatter_state_bytes, void *stream);
+size_t okge_pool_scatter_state_bytes(const okge_pool_call *calls, int32_t n_calls);
+size_t okge_pool_backward_workspace_bytes(const okge_pool_call *calls, int32_t n_calls);
 size_t okge_pool_workspace_bytes(int32_t n, int32_t d);
 int okge_pool_encode(const okge_token_embedder *e, const int32_t *ids, int32_t first_id, int32_t n, int32_t training,
                      float *raw, float *out, int64_t ld, float *saved, void *workspace, size_t workspace_bytes,
@@ -317,6 +332,20 @@ int okge_adagrad_step(float *p, float *g, float *state_sum, int64_t n, float lr,
  * candidate are never written and stay zero), so clearing 4*|E|*d bytes per step would be wasted traffic. */
 int okge_adagrad_step2(float *p0, float *g0, float *sum0, int64_t n0, float *p1, float *g1, float *sum1,
                        int64_t n1, float lr, float weight_decay, float eps, int32_t zero_grad, void *stream);
+
+/* The same update on up to four tensors in ONE launch (token tables + batch-norm parameters of the token-pooled models).
+ * row_touched (optional, needs zero_grad and n % row_len == 0, row_len % 4 == 0): a byte per row of row_len floats; a row
+ * whose byte differs from touched_stamp holds an all-zero gradient BY CONTRACT (okge_pool_backward_calls stamps every row it
+ * writes) and its gradient is neither read nor cleared -- the row still takes the reference's weight-decay-only update
+ * (utils/optim.py:139-160 applies wd to all rows).  The map is not erased: use another stamp (1..255) for the next update. */
+typedef struct okge_adagrad_tensor {
+    float *p, *g, *state_sum;
+    int64_t n;
+    const uint8_t *row_touched;
+    int32_t row_len, touched_stamp, zero_grad, _pad;
+} okge_adagrad_tensor;
+int okge_adagrad_multi(const okge_adagrad_tensor *tensors, int32_t n_tensors, float lr, float weight_decay, float eps,
+                       void *stream);
 
 /* ---- batch producer (HOST pointers; no device work) ---------------------------------------------------
  * Replaces OneToNMentionRelationDataset_collate_func (dataset.py:724-940) and the packed answer-group decoding

@@ -32,7 +32,7 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_score_workspace_bytes", "okge_lse_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_prefix_backward_segmented", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
-           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_shard", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward", "okge_pool_encode_calls", "okge_pool_backward_calls",
+           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_shard", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward", "okge_pool_encode_calls", "okge_pool_backward_calls", "okge_pool_scatter_state_bytes", "okge_pool_backward_workspace_bytes", "okge_adagrad_multi",
            "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
            "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_rescale_gradients", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
@@ -86,7 +86,13 @@ class TokenEmbedder(Structure):
 class PoolCall(Structure):
     _fields_ = [("e", POINTER(TokenEmbedder)), ("ids", c_void_p), ("first_id", c_int32), ("n", c_int32), ("raw", c_void_p),
                 ("out", c_void_p), ("ld", c_int64), ("saved", c_void_p), ("d_out", c_void_p), ("dW", c_void_p),
-                ("d_bn_weight", c_void_p), ("d_bn_bias", c_void_p)]
+                ("d_bn_weight", c_void_p), ("d_bn_bias", c_void_p), ("row_touched", c_void_p), ("touched_stamp", c_int32),
+                ("_pad", c_int32)]
+
+
+class AdagradTensor(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("state_sum", c_void_p), ("n", c_int64), ("row_touched", c_void_p),
+                ("row_len", c_int32), ("touched_stamp", c_int32), ("zero_grad", c_int32), ("_pad", c_int32)]
 
 
 class PrefixTable(Structure):
@@ -257,7 +263,13 @@ def lib():
     L.okge_pool_encode_calls.restype = c_int32
     L.okge_pool_encode_calls.argtypes = [POINTER(PoolCall), c_int32, c_int32, c_void_p, c_size_t, c_void_p]
     L.okge_pool_backward_calls.restype = c_int32
-    L.okge_pool_backward_calls.argtypes = [POINTER(PoolCall), c_int32, c_void_p, c_size_t, c_void_p]
+    L.okge_pool_backward_calls.argtypes = [POINTER(PoolCall), c_int32, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
+    L.okge_pool_scatter_state_bytes.restype = c_size_t
+    L.okge_pool_scatter_state_bytes.argtypes = [POINTER(PoolCall), c_int32]
+    L.okge_pool_backward_workspace_bytes.restype = c_size_t
+    L.okge_pool_backward_workspace_bytes.argtypes = [POINTER(PoolCall), c_int32]
+    L.okge_adagrad_multi.restype = c_int32
+    L.okge_adagrad_multi.argtypes = [POINTER(AdagradTensor), c_int32, c_float, c_float, c_float, c_void_p]
     L.okge_scale_inplace.restype = c_int32
     L.okge_scale_inplace.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.okge_rescale_gradients.restype = c_int32

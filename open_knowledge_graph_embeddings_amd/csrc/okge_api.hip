@@ -918,7 +918,7 @@ static int pool_call_dev(const okge_pool_call &c, bool backward, bool training, 
     const bool bn = e->bn_weight != nullptr;
     std::memset(&q, 0, sizeof(q));
     q.W = e->W; q.tokens = e->token_ids; q.ids = c.ids; q.raw = c.raw; q.out = c.out; q.ld = c.ld;
-    q.d = e->d; q.L = e->max_len; q.first_id = c.first_id; q.n = c.n; q.pool = e->pool; q.n_ids = e->n_ids;
+    q.d = e->d; q.L = e->max_len; q.first_id = c.first_id; q.n = c.n; q.pool = e->pool; q.n_ids = e->n_ids; q.vocab = e->vocab;
     q.eps = e->bn_eps; q.momentum = e->bn_momentum;
     q.bn_weight = e->bn_weight; q.bn_bias = e->bn_bias; q.run_mean = e->bn_running_mean; q.run_var = e->bn_running_var;
     if (!backward) {
@@ -934,6 +934,9 @@ static int pool_call_dev(const okge_pool_call &c, bool backward, bool training, 
             return fail(OKGE_ERR_INVALID, "batch-norm backward needs saved statistics and gradient buffers");
         q.saved = bn ? c.saved : nullptr;
         q.dY = c.d_out; q.dW = c.dW; q.d_weight = c.d_bn_weight; q.d_bias = c.d_bn_bias;
+        if (c.row_touched && (c.touched_stamp < 1 || c.touched_stamp > 255))
+            return fail(OKGE_ERR_INVALID, "touched_stamp must lie in 1..255");
+        q.touched = c.row_touched; q.touched_stamp = c.touched_stamp;
     }
     if (q.saved) {
         const size_t need = pool_workspace_bytes(c.n, e->d);
@@ -961,7 +964,38 @@ int okge_pool_encode_calls(const okge_pool_call *calls, int32_t n_calls, int32_t
     return OKGE_OK;
 }
 
-int okge_pool_backward_calls(const okge_pool_call *calls, int32_t n_calls, void *workspace, size_t workspace_bytes, void *stream)
+// the calls as the kernels see them, without workspace shares (sizing only)
+static int pool_calls_for_sizing(const okge_pool_call *calls, int32_t n_calls, PoolCall *q)
+{
+    if (!calls || n_calls <= 0 || n_calls > POOL_MAX_CALLS) return fail(OKGE_ERR_INVALID, "1 to 8 pooled calls per batch");
+    for (int i = 0; i < n_calls; ++i) {
+        const okge_token_embedder *e = calls[i].e;
+        if (int rc = check_token_embedder(e, calls[i].ids, calls[i].first_id, calls[i].n)) return rc;
+        std::memset(&q[i], 0, sizeof(PoolCall));
+        q[i].tokens = e->token_ids; q[i].d = e->d; q[i].L = e->max_len; q[i].n = calls[i].n; q[i].pool = e->pool;
+        q[i].vocab = e->vocab; q[i].dW = calls[i].dW; q[i].touched = calls[i].row_touched;
+    }
+    return OKGE_OK;
+}
+
+size_t okge_pool_scatter_state_bytes(const okge_pool_call *calls, int32_t n_calls)
+{
+    PoolCall q[POOL_MAX_CALLS];
+    if (pool_calls_for_sizing(calls, n_calls, q)) return 0;
+    return pool_scatter_state_bytes(q, n_calls);
+}
+
+size_t okge_pool_backward_workspace_bytes(const okge_pool_call *calls, int32_t n_calls)
+{
+    PoolCall q[POOL_MAX_CALLS];
+    if (pool_calls_for_sizing(calls, n_calls, q)) return 0;
+    size_t bytes = pool_scatter_workspace_bytes(q, n_calls);
+    for (int i = 0; i < n_calls; ++i) bytes += pool_workspace_bytes(calls[i].n, calls[i].e->d);
+    return bytes;
+}
+
+int okge_pool_backward_calls(const okge_pool_call *calls, int32_t n_calls, void *workspace, size_t workspace_bytes,
+                             void *scatter_state, size_t scatter_state_bytes, void *stream)
 {
     if (!calls || n_calls <= 0 || n_calls > POOL_MAX_CALLS) return fail(OKGE_ERR_INVALID, "1 to 8 pooled calls per batch");
     PoolCall q[POOL_MAX_CALLS];
@@ -969,9 +1003,19 @@ int okge_pool_backward_calls(const okge_pool_call *calls, int32_t n_calls, void 
     size_t left = workspace_bytes;
     for (int i = 0; i < n_calls; ++i)
         if (int rc = pool_call_dev(calls[i], true, true, ws, left, q[i])) return rc;
+    if (scatter_state) {
+        const size_t need_state = pool_scatter_state_bytes(q, n_calls), need_ws = pool_scatter_workspace_bytes(q, n_calls);
+        if (!need_state)
+            return fail(OKGE_ERR_UNSUPPORTED, "the scatter plan needs sum / mean pooling, slot sizes that are a multiple of 4 and calls "
+                                              "of one token table to agree in token matrix and touched map (pass scatter_state = NULL)");
+        if (scatter_state_bytes < need_state) return fail(OKGE_ERR_WORKSPACE, "scatter state too small (okge_pool_scatter_state_bytes)");
+        if (!ws || left < need_ws) return fail(OKGE_ERR_WORKSPACE, "workspace too small (okge_pool_backward_workspace_bytes)");
+        if (reinterpret_cast<uintptr_t>(scatter_state) % 16 || reinterpret_cast<uintptr_t>(ws) % 16)
+            return fail(OKGE_ERR_INVALID, "scatter state and workspace must be 16-byte aligned");
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ScopedTimer tm("pool_backward", st);
-    hipError_t err = launch_pool_backward_calls(q, n_calls, id_err_ptr(), st);
+    hipError_t err = launch_pool_backward_calls(q, n_calls, id_err_ptr(), st, scatter_state, scatter_state_bytes, scatter_state ? ws : nullptr, left);
     if (err != hipSuccess) return fail_hip(err, "pool_backward");
     return OKGE_OK;
 }
@@ -998,7 +1042,7 @@ int okge_pool_backward(const okge_token_embedder *e, const int32_t *ids, int32_t
     std::memset(&c, 0, sizeof(c));
     c.e = e; c.ids = ids; c.first_id = first_id; c.n = n; c.raw = const_cast<float *>(raw); c.ld = ld; c.saved = saved;
     c.d_out = d_out; c.dW = dW; c.d_bn_weight = d_bn_weight; c.d_bn_bias = d_bn_bias;
-    return okge_pool_backward_calls(&c, 1, workspace, workspace_bytes, stream);
+    return okge_pool_backward_calls(&c, 1, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 int okge_scale_inplace(float *x, int64_t n, const float *alpha_dev, void *stream)
@@ -1046,6 +1090,30 @@ int okge_adagrad_step2(float *p0, float *g0, float *sum0, int64_t n0, float *p1,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ScopedTimer tm("adagrad", st);
     hipError_t e = launch_adagrad2(p0, g0, sum0, n0, p1, g1, sum1, n1, lr, weight_decay, eps, zero_grad, st);
+    if (e != hipSuccess) return fail_hip(e, "adagrad");
+    return OKGE_OK;
+}
+
+int okge_adagrad_multi(const okge_adagrad_tensor *tensors, int32_t n_tensors, float lr, float weight_decay, float eps, void *stream)
+{
+    if (!tensors || n_tensors <= 0 || n_tensors > ADAGRAD_MAX_SEGS) return fail(OKGE_ERR_INVALID, "1 to 4 tensors per adagrad launch");
+    AdagradSegM segs[ADAGRAD_MAX_SEGS];
+    for (int i = 0; i < n_tensors; ++i) {
+        const okge_adagrad_tensor &t = tensors[i];
+        if (!t.p || !t.g || !t.state_sum || t.n < 0) return fail(OKGE_ERR_INVALID, "bad adagrad arguments");
+        if ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.state_sum)) % 16)
+            return fail(OKGE_ERR_INVALID, "adagrad buffers must be 16-byte aligned");
+        if (t.row_touched) {
+            if (t.row_len <= 0 || t.row_len % 4 || t.n % t.row_len || t.n / t.row_len > INT32_MAX)
+                return fail(OKGE_ERR_INVALID, "a touched-row map needs rows of a multiple of 4 floats that tile the tensor");
+            if (t.touched_stamp < 1 || t.touched_stamp > 255) return fail(OKGE_ERR_INVALID, "touched_stamp must lie in 1..255");
+            if (!t.zero_grad) return fail(OKGE_ERR_INVALID, "a touched-row map needs zero_grad (rows not stamped must hold zero gradients)");
+        }
+        segs[i] = AdagradSegM{t.p, t.g, t.state_sum, t.n, t.row_touched, t.row_len, t.touched_stamp, t.zero_grad, 0};
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("adagrad", st);
+    hipError_t e = launch_adagrad_multi(segs, n_tensors, lr, weight_decay, eps, st);
     if (e != hipSuccess) return fail_hip(e, "adagrad");
     return OKGE_OK;
 }

@@ -148,13 +148,24 @@ struct PoolCall {
     float         *run_mean, *run_var;
     float         *d_weight, *d_bias, *dW;  // backward targets
     float         *partial;                 // [ceil(n / 32)][2][d] scratch of this call
+    uint8_t       *touched;                 // backward: [vocab] bytes, touched[token] = touched_stamp for every row of dW written (or nullptr)
     int64_t        ld;
-    int32_t        d, L, first_id, n, pool, n_ids;
+    int32_t        d, L, first_id, n, pool, n_ids, vocab, touched_stamp;
     float          eps, momentum;
 };
 size_t pool_workspace_bytes(int n, int d);
 hipError_t launch_pool_encode_calls(const PoolCall *calls, int n_calls, int training, int *id_err, hipStream_t st);
-hipError_t launch_pool_backward_calls(const PoolCall *calls, int n_calls, int *id_err, hipStream_t st);
+// state == nullptr: the token-table gradient is scattered with float atomics; otherwise (pool sum / mean, slot sizes that are
+// a multiple of 4): store-and-sum through a device-built inverted index, bit-reproducible (okge_pool.hip, "scatter plan")
+size_t pool_scatter_state_bytes(const PoolCall *calls, int n_calls);
+size_t pool_scatter_workspace_bytes(const PoolCall *calls, int n_calls);
+hipError_t launch_pool_backward_calls(const PoolCall *calls, int n_calls, int *id_err, hipStream_t st, void *state = nullptr,
+                                      size_t state_bytes = 0, void *scratch = nullptr, size_t scratch_bytes = 0);
+// dense Adagrad over up to four tensors in one launch; a tensor may come with a touched-row byte map (rows whose byte differs
+// from `stamp` hold an all-zero gradient by contract: it is neither read nor cleared)
+constexpr int ADAGRAD_MAX_SEGS = 4;
+struct AdagradSegM { float *p, *g, *s; int64_t n; const uint8_t *touched; int32_t row_len, stamp, zero_grad, _pad; };
+hipError_t launch_adagrad_multi(const AdagradSegM *segs, int n_segs, float lr, float wd, float eps, hipStream_t st);
 hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
                             int cand_first, int exclusive, int grads_zero, float *dE, int64_t table_rows, int *id_err,
                             hipStream_t st);

@@ -6,6 +6,8 @@
 //   adagrad_kernel          dense Adagrad sweep (+ zero_grad)                          utils/optim.py:139-160 / torch.optim.Adagrad
 //   ranks_kernel            filtered ranks, exact integer counts                       dataset.py:423-446
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "okge_device.h"
 #include "okge_kernels.h"
@@ -679,6 +681,89 @@ __global__ __launch_bounds__(256) void adagrad2_kernel(const AdagradSeg a, const
     adagrad_sweep(b, lr, wd, eps, zero_grad != 0, first, stride);
 }
 
+// Up to four tensors in one launch (token tables + batch-norm parameters of a token-pooled step: one launch instead of two),
+// each optionally with a touched-row byte map: a row whose byte differs from the segment's stamp holds an all-zero gradient
+// by contract (the pooling backward stamps every row it writes, okge_pool.hip pass 4), so its gradient is neither read nor
+// cleared -- such rows still run through the arithmetic (the reference's wd * p reaches ALL rows) on p and sum alone.
+// The stamp is never erased: the caller moves to another stamp after every update (a stale byte that meets its stamp again
+// 255 updates later only costs the read of a gradient row that is zero).
+struct AdagradSegsDev { AdagradSegM s[ADAGRAD_MAX_SEGS]; int n, unroll; };
+
+// (U iterations of the grid-stride loop side by side: the map byte decides whether the gradient is loaded at all, so one
+//  iteration is TWO dependent round trips -- run one at a time the sweep was latency-bound, slower than the map-less one)
+template <int U, bool MAP>
+__device__ __forceinline__ void adagrad_sweep_map(const AdagradSegM sg, float lr, float wd, float eps, int64_t first, int64_t stride)
+{
+    const int64_t n4 = sg.n >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(sg.p), *g4 = reinterpret_cast<float4 *>(sg.g), *s4 = reinterpret_cast<float4 *>(sg.s);
+    const uint32_t row4 = MAP ? (uint32_t)(sg.row_len >> 2) : 1u;
+    const int shift = (row4 & (row4 - 1)) == 0 ? 31 - __clz(row4) : -1;
+    const uint8_t stamp = (uint8_t)sg.stamp;
+    for (int64_t i0 = first; i0 < n4; i0 += U * stride) {
+        bool ok[U], live[U];
+        float4 pv[U], sv[U], gv[U];
+        uint8_t mb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                            // the U map bytes first, no branch between the loads
+            const int64_t i = min(i0 + u * stride, n4 - 1);
+            ok[u] = i0 + u * stride < n4;
+            mb[u] = stamp;
+            if (MAP) mb[u] = sg.touched[shift >= 0 ? (uint32_t)i >> shift : (uint32_t)i / row4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) live[u] = ok[u] && mb[u] == stamp;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            pv[u] = sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) { pv[u] = p4[i]; sv[u] = s4[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live[u]) gv[u] = g4[i0 + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            const int64_t i = i0 + u * stride;
+            const float4 p_old = pv[u], s_old = sv[u];
+            float *pp = &pv[u].x, *gg = &gv[u].x, *ss = &sv[u].x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gj = fmaf(wd, pp[j], gg[j]);
+                ss[j] = fmaf(gj, gj, ss[j]);
+                pp[j] = pp[j] - lr * (gj / (sqrtf(ss[j]) + eps));
+            }
+            if (bits_differ(pv[u], p_old)) p4[i] = pv[u];            // (store only what changed: see adagrad_sweep)
+            if (bits_differ(sv[u], s_old)) s4[i] = sv[u];
+            if (live[u] && sg.zero_grad && ((__float_as_uint(gv[u].x) | __float_as_uint(gv[u].y) | __float_as_uint(gv[u].z) | __float_as_uint(gv[u].w)) != 0u))
+                g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (first < (sg.n & 3)) {                                    // (tail: only tensors without a map have one)
+        const int64_t i = (n4 << 2) + first;
+        const float gj = fmaf(wd, sg.p[i], sg.g[i]);
+        sg.s[i] = fmaf(gj, gj, sg.s[i]);
+        sg.p[i] = sg.p[i] - lr * (gj / (sqrtf(sg.s[i]) + eps));
+        if (sg.zero_grad) sg.g[i] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void adagrad_multi_kernel(const AdagradSegsDev segs, float lr, float wd, float eps)
+{
+    const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int k = 0; k < ADAGRAD_MAX_SEGS; ++k)
+        if (k < segs.n) {
+            if (segs.s[k].touched) {
+                if (segs.unroll == 4) adagrad_sweep_map<4, true>(segs.s[k], lr, wd, eps, first, stride);
+                else if (segs.unroll == 2) adagrad_sweep_map<2, true>(segs.s[k], lr, wd, eps, first, stride);
+                else adagrad_sweep_map<1, true>(segs.s[k], lr, wd, eps, first, stride);
+            } else adagrad_sweep_map<1, false>(segs.s[k], lr, wd, eps, first, stride);
+        }
+}
+
 constexpr int RANK_GROUPS = 8;
 
 // Count, for NG answer groups of one row at once, how many (filter-corrected) scores are greater than / equal to
@@ -1154,6 +1239,26 @@ hipError_t launch_adagrad2(float *p0, float *g0, float *s0, int64_t n0, float *p
     const int blocks = (int)std::min((int64_t)16384, (n4 + 255) / 256);
     const AdagradSeg a{p0, g0, s0, n0}, b{p1, g1, s1, n1};
     hipLaunchKernelGGL(adagrad2_kernel, dim3(blocks), dim3(256), 0, st, a, b, lr, wd, eps, zero_grad);
+    return hipGetLastError();
+}
+
+hipError_t launch_adagrad_multi(const AdagradSegM *segs, int n_segs, float lr, float wd, float eps, hipStream_t st)
+{
+    if (n_segs <= 0) return hipSuccess;
+    if (n_segs > ADAGRAD_MAX_SEGS) return hipErrorInvalidValue;
+    AdagradSegsDev a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = n_segs;
+    static const int unroll = getenv("OKGE_ADAGRAD_U") ? atoi(getenv("OKGE_ADAGRAD_U")) : 4;
+    a.unroll = unroll;
+    int64_t n4 = 0;
+    for (int k = 0; k < n_segs; ++k) {
+        a.s[k] = segs[k];
+        n4 = std::max(n4, (segs[k].n + 3) / 4);
+    }
+    if (n4 <= 0) return hipSuccess;
+    const int blocks = (int)std::min((int64_t)16384, (n4 + 255) / 256);
+    hipLaunchKernelGGL(adagrad_multi_kernel, dim3(blocks), dim3(256), 0, st, a, lr, wd, eps);
     return hipGetLastError();
 }
 

@@ -429,6 +429,18 @@ class HotPath:
                                             g1.data_ptr(), s1.data_ptr(), p1.numel(), float(lr), float(weight_decay),
                                             float(eps), int(zero_grad), self._stream()), "okge_adagrad_step2")
 
+    def adagrad_multi(self, tensors, lr, weight_decay=1e-10, eps=1e-8):
+        """One launch over up to four (p, g, state_sum[, touched_map, stamp]) tuples, gradients cleared in the sweep
+        (okge_adagrad_multi): a tensor with a touched-row byte map skips the gradient rows the map does not stamp."""
+        arr = (N.AdagradTensor * len(tensors))()
+        for a, t in zip(arr, tensors):
+            p, g, s = t[:3]
+            a.p, a.g, a.state_sum, a.n, a.zero_grad = p.data_ptr(), g.data_ptr(), s.data_ptr(), p.numel(), 1
+            if len(t) > 3 and t[3] is not None:
+                a.row_touched, a.row_len, a.touched_stamp = t[3].data_ptr(), p.shape[1], int(t[4])
+        N.check(self.lib.okge_adagrad_multi(arr, len(tensors), float(lr), float(weight_decay), float(eps), self._stream()),
+                "okge_adagrad_multi")
+
     def clip_grad_norm_(self, g0, g1, max_norm, norm_out=None):
         """torch.nn.utils.clip_grad_norm_ over two dense gradient tensors, in place (trainer.py:236-240)"""
         if getattr(self, "_clip_ws", None) is None:

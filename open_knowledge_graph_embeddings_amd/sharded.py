@@ -468,12 +468,15 @@ class ReplicaStep:
                 g = self.grads[i]
                 span = self.flat[off:off + rows.numel() * g.shape[1]].view(rows.numel(), g.shape[1])
                 torch.index_select(g, 0, rows, out=span)
-                spans.append((g, rows, span))
+                spans.append((g, rows, span, i))
                 off += span.numel()
             dist.all_reduce(self.flat[:off], group=self.group)
             self.last_exchanged_elements = off
-            for g, rows, span in spans:
+            mark = getattr(self.inner, "mark_sparse_rows", None)
+            for g, rows, span, i in spans:
                 g.index_copy_(0, rows, span)
+                if mark is not None:                    # rows other replicas touched: the optimizer's touched-row map must know
+                    mark(i, rows)
         if self.stats:
             self.flat[self._n_dense_grad:self._small].mul_(1.0 / self.world)
         if loss is not None:

@@ -12,6 +12,7 @@ statistics; that order is kept.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -52,6 +53,13 @@ class TokenSlot:
             self.sum_bn = torch.zeros(2 * d, dtype=torch.float32, device=dev)
         self.dW = torch.zeros_like(W)
         self.sumW = torch.zeros_like(W)
+        # touched-row map of dW for the optimizer sweep: the pooling backward stamps every row it writes, okge_adagrad_multi
+        # skips the gradient rows that do not carry the current stamp (okge.h); the stamp moves on after every update
+        self.touched = torch.zeros(W.shape[0], dtype=torch.uint8, device=dev) if d % 4 == 0 else None
+        self.stamp = 1
+
+    def next_stamp(self):
+        self.stamp = self.stamp % 255 + 1
 
     @property
     def bn_weight(self):
@@ -80,6 +88,7 @@ class PoolEngine:
         self.device = torch.device(device)
         self.lib = N.lib()
         self._ws, self._ws_bytes = None, 0
+        self._state, self._state_bytes = None, 0
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -118,7 +127,7 @@ class PoolEngine:
 
     # -- a batch of _encode calls in one go (okge_pool_encode_calls / okge_pool_backward_calls) ----------------------
     def _calls(self, calls, backward):
-        """calls: [(slot, ids, first_id, n, raw, out_or_d_out, saved)] with n > 0 -> (ctypes array, keep-alive list, workspace)"""
+        """calls: [(slot, ids, first_id, n, raw, out_or_d_out, saved)] with n > 0 -> (ctypes array, keep-alive list)"""
         arr = (N.PoolCall * len(calls))()
         keep, need = [], 0
         for x, (slot, ids, first_id, n, raw, other, saved) in zip(arr, calls):
@@ -132,13 +141,29 @@ class PoolEngine:
                 x.d_out, x.dW = other.data_ptr(), slot.dW.data_ptr()
                 if slot.bn is not None:
                     x.d_bn_weight, x.d_bn_bias = slot.d_bn[:slot.d].data_ptr(), slot.d_bn[slot.d:].data_ptr()
+                touched = getattr(slot, "touched", None)
+                if touched is not None:
+                    x.row_touched, x.touched_stamp = touched.data_ptr(), int(slot.stamp)
             else:
                 x.out = other.data_ptr()
             need += int(self.lib.okge_pool_workspace_bytes(int(n), slot.d))
+        if backward and self.scatter_plan(calls):
+            need = int(self.lib.okge_pool_backward_workspace_bytes(arr, len(calls)))
+            state = int(self.lib.okge_pool_scatter_state_bytes(arr, len(calls)))
+            if state > self._state_bytes:
+                # zeroed ONCE: the kernels leave the state zero (okge.h); a graph capture must not allocate
+                self._state = torch.zeros(state, dtype=torch.uint8, device=self.device)
+                self._state_bytes = state
         if need > self._ws_bytes:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             self._ws_bytes = need
         return arr, keep
+
+    def scatter_plan(self, calls):
+        """store-and-sum scatter (bit-reproducible, okge.h) where it applies; OKGE_POOL_SCATTER=atomics keeps the old path"""
+        if os.environ.get("OKGE_POOL_SCATTER", "plan") == "atomics":
+            return False
+        return all(c[0].pool != "max" and c[0].d % 4 == 0 for c in calls)
 
     def encode_calls(self, calls, training):
         calls = [c for c in calls if c[3] > 0]
@@ -154,8 +179,10 @@ class PoolEngine:
         if not calls:
             return
         arr, keep = self._calls(calls, True)
-        N.check(self.lib.okge_pool_backward_calls(arr, len(calls), None if self._ws is None else self._ws.data_ptr(),
-                                                  self._ws_bytes, self._stream()), "okge_pool_backward_calls")
+        plan = self.scatter_plan(calls)
+        N.check(self.lib.okge_pool_backward_calls(arr, len(calls), None if self._ws is None else self._ws.data_ptr(), self._ws_bytes,
+                                                  self._state.data_ptr() if plan else None, self._state_bytes if plan else 0,
+                                                  self._stream()), "okge_pool_backward_calls")
         del keep
 
 
@@ -287,15 +314,20 @@ class TokenPooledTrainStep:
         pe.backward_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[6], c_[7]) for c_ in calls])
         return self.loss_out
 
+    def mark_sparse_rows(self, index, rows):
+        """sharded.ReplicaStep wrote other replicas' gradient rows into a sparse gradient (grad_tensors()[index]): stamp them"""
+        sl = self.entity if index == self.sparse_grad_indices()[0] else self.relation
+        if sl.touched is not None:
+            sl.touched.index_fill_(0, rows.reshape(-1).long(), sl.stamp)
+
     def optimizer_step(self):
         eng, e, r = self.engine, self.entity, self.relation
-        eng.adagrad2(e.W, e.dW, e.sumW, r.W, r.dW, r.sumW, self.lr, self.weight_decay, self.eps, zero_grad=True)
-        if e.bn is not None and r.bn is not None:
-            eng.adagrad2(e.bn, e.d_bn, e.sum_bn, r.bn, r.d_bn, r.sum_bn, self.lr, self.weight_decay, self.eps, zero_grad=True)
-        else:
-            for sl in (e, r):
-                if sl.bn is not None:
-                    eng.adagrad(sl.bn, sl.d_bn, sl.sum_bn, self.lr, self.weight_decay, self.eps, zero_grad=True)
+        # one launch: token tables (gradient rows the backward did not stamp are neither read nor cleared) + batch-norm parameters
+        tensors = [(sl.W, sl.dW, sl.sumW, sl.touched, sl.stamp) for sl in (e, r)]
+        tensors += [(sl.bn, sl.d_bn, sl.sum_bn) for sl in (e, r) if sl.bn is not None]
+        eng.adagrad_multi(tensors, self.lr, self.weight_decay, self.eps)
+        for sl in (e, r):
+            sl.next_stamp()
         for sl, bn in getattr(self, "module_batchnorms", ()):          # keep an attached nn.Module's parameters current
             bn.weight.data.copy_(sl.bn_weight)
             bn.bias.data.copy_(sl.bn_bias)

@@ -182,3 +182,113 @@ def test_random_token_pooled_step_vs_oracle(okge_lib, i):
     if bn:
         np.testing.assert_allclose(e.d_bn[:d].cpu().numpy(), ref["d_bn_ent"][0], rtol=0, atol=2e-4 * np.abs(ref["d_bn_ent"][0]).max() + 1e-7)
         np.testing.assert_allclose(e.running_var.cpu().numpy(), bn_e["running_var"], rtol=1e-4, atol=1e-6)
+
+
+# ---- round 4: the token-table gradient as store-and-sum through a device-built inverted index (okge_pool.hip "scatter plan") ----
+def _plan_case(rng, d, L, n_ent, vt_e, N, n_po, n_sp, pool="sum", bn=False, hot_frac=0.3, mid_tokens=()):
+    """token matrices with a chosen mix: ids < 32 (LDS slabs), a few mid-frequency ids >= 32 that land in MANY rows
+    (segments longer than one wave sorts: the bitmap path), rare ids (wave-sorted segments), repeats inside a row"""
+    def tokens(n, vocab):
+        m = np.zeros((n, L), np.int32)
+        for r in range(n):
+            k = int(rng.integers(1, L + 1))
+            row = rng.integers(32, vocab, k)
+            hot = rng.random(k) < hot_frac
+            row[hot] = rng.integers(1, 32, int(hot.sum()))
+            for t in mid_tokens:
+                if rng.random() < 0.5:
+                    row[int(rng.integers(0, k))] = t
+            if k > 1 and rng.random() < 0.3:
+                row[1] = row[0]                                   # the same token twice in one row: two pairs
+            m[r, :k] = row
+        return m
+    n_rel, vt_r = 40, 50
+    ent_tok = tokens(n_ent, vt_e)
+    mid_tokens = (45,) if mid_tokens else ()                  # (the relation vocabulary is smaller)
+    rel_tok = tokens(n_rel, vt_r)
+    We = (rng.standard_normal((vt_e, d)) * 0.3).astype(np.float32)
+    Wr = (rng.standard_normal((vt_r, d)) * 0.3).astype(np.float32)
+    cand = rng.integers(2, n_ent, N).astype(np.int32)
+    po = (rng.integers(2, n_rel, n_po).astype(np.int32), rng.integers(2, n_ent, n_po).astype(np.int32))
+    sp = (rng.integers(2, n_ent, n_sp).astype(np.int32), rng.integers(2, n_rel, n_sp).astype(np.int32))
+    B = n_po + n_sp
+    y = np.zeros((B, N), np.float32)
+    y[np.arange(B), rng.integers(0, N, B)] = 1
+    mk_bn = lambda: dict(weight=rng.random(d).astype(np.float32), bias=(rng.standard_normal(d) * 0.1).astype(np.float32),   # noqa: E731
+                         running_mean=np.zeros(d, np.float32), running_var=np.ones(d, np.float32))
+    return dict(We=We, Wr=Wr, ent_tok=ent_tok, rel_tok=rel_tok, cand=cand, po=po, sp=sp, y=y, pool=pool,
+                bn_e=mk_bn() if bn else None, bn_r=mk_bn() if bn else None)
+
+
+def _plan_step(c, scorer="complex"):
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch, positives_from_dense
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    bn = c["bn_e"] is not None
+    e = TokenSlot(dev(c["We"]), dev(c["ent_tok"]), c["pool"], bn, dev(c["bn_e"]["weight"]) if bn else None, dev(c["bn_e"]["bias"]) if bn else None)
+    r = TokenSlot(dev(c["Wr"]), dev(c["rel_tok"]), c["pool"], bn, dev(c["bn_r"]["weight"]) if bn else None, dev(c["bn_r"]["bias"]) if bn else None)
+    st = TokenPooledTrainStep(e, r, scorer)
+    b = PrefixBatch(cand_ids=dev(c["cand"]), po_rel=dev(c["po"][0]), po_obj=dev(c["po"][1]), sp_subj=dev(c["sp"][0]), sp_rel=dev(c["sp"][1]))
+    b.pos_row, b.pos_col = positives_from_dense(dev(c["y"]))
+    return st, e, r, b
+
+
+@pytest.mark.parametrize("case", ["short", "long_one_window", "long_two_windows", "mean_bn", "d256_bn"])
+def test_scatter_plan_matches_oracle_and_is_bit_reproducible(okge_lib, monkeypatch, case):
+    """the same step three times from cleared gradients: token-table gradients EQUAL bit for bit (the atomics' sums moved in
+    the last bits), within tolerance of the float64 oracle and of the atomics path; every segment class is met"""
+    rng = np.random.default_rng({"short": 1, "long_one_window": 2, "long_two_windows": 3, "mean_bn": 4, "d256_bn": 5}[case])
+    if case == "short":
+        c = _plan_case(rng, d=8, L=5, n_ent=300, vt_e=4000, N=200, n_po=30, n_sp=20)
+    elif case == "long_one_window":
+        c = _plan_case(rng, d=24, L=6, n_ent=900, vt_e=600, N=1500, n_po=100, n_sp=90, mid_tokens=(40, 77, 311))
+    elif case == "long_two_windows":                           # (N + B) * L = 8 200 * 17 > 131 072 pair indices
+        c = _plan_case(rng, d=8, L=17, n_ent=5000, vt_e=3000, N=7000, n_po=700, n_sp=500, mid_tokens=(33, 1500))
+    elif case == "mean_bn":
+        c = _plan_case(rng, d=64, L=4, n_ent=500, vt_e=200, N=700, n_po=64, n_sp=64, pool="mean", bn=True, mid_tokens=(50,))
+    else:
+        c = _plan_case(rng, d=256, L=10, n_ent=800, vt_e=900, N=600, n_po=70, n_sp=70, bn=True, mid_tokens=(64,))
+    kind = ko.COMPLEX
+    ref = ko.unigram_step_forward_backward(kind, c["We"], c["Wr"], c["ent_tok"], c["rel_tok"], c["po"], c["sp"], c["cand"], c["y"],
+                                           pool=c["pool"], bn_ent=c["bn_e"], bn_rel=c["bn_r"])
+    st, e, r, b = _plan_step(c)
+    runs = []
+    for _ in range(3):
+        e.dW.zero_(); r.dW.zero_()
+        st.forward_backward(b)
+        torch.cuda.synchronize()
+        runs.append((e.dW.clone(), r.dW.clone()))
+    for dWe, dWr in runs[1:]:
+        assert torch.equal(dWe, runs[0][0]) and torch.equal(dWr, runs[0][1])
+    for mine, want in ((runs[0][0], ref["dWe"]), (runs[0][1], ref["dWr"])):
+        np.testing.assert_allclose(mine.cpu().numpy(), want, rtol=0, atol=2e-4 * np.abs(want).max() + 1e-7)
+    # every stamped row and only those: rows with a gradient carry the stamp
+    for sl, dW in ((e, runs[0][0]), (r, runs[0][1])):
+        nz = (dW != 0).any(dim=1)
+        stamped = sl.touched == sl.stamp
+        assert bool((stamped | ~nz).all()), "a row with a gradient is not stamped"
+    # the atomics path on the same inputs
+    monkeypatch.setenv("OKGE_POOL_SCATTER", "atomics")
+    st2, e2, r2, b2 = _plan_step(c)
+    st2.forward_backward(b2)
+    torch.cuda.synchronize()
+    for a, o in ((e2.dW, runs[0][0]), (r2.dW, runs[0][1])):
+        np.testing.assert_allclose(a.cpu().numpy(), o.cpu().numpy(), rtol=0, atol=1e-5 * float(o.abs().max()) + 1e-9)
+    from open_knowledge_graph_embeddings_amd import _native as N
+    N.check_ids()
+
+
+def test_touched_map_adagrad_is_bit_equal_to_the_dense_sweep(okge_lib):
+    """three optimisation steps with the touched-row map (gradient rows no token named are neither read nor cleared) against
+    the same steps with the map switched off: tables and accumulators bit-equal"""
+    rng = np.random.default_rng(11)
+    c = _plan_case(rng, d=64, L=5, n_ent=400, vt_e=3000, N=300, n_po=40, n_sp=40, bn=True, mid_tokens=(45,))
+    a = _plan_step(c)
+    b_ = _plan_step(c)
+    b_[1].touched = b_[2].touched = None                         # dense sweep: every gradient row is read
+    for _ in range(3):
+        a[0].step(a[3])
+        b_[0].step(b_[3])
+    torch.cuda.synchronize()
+    for x, y in ((a[1], b_[1]), (a[2], b_[2])):
+        assert torch.equal(x.W, y.W) and torch.equal(x.sumW, y.sumW) and torch.equal(x.bn, y.bn)
+        assert float(x.dW.abs().max()) == 0.0                    # cleared where stamped, zero elsewhere

@@ -150,7 +150,7 @@ def main():
     for world in (2, 4, 8):
         if f"S-FB-rank{world}" in which:
             rank_shape(world, dev, t)
-    if "S-OLP-tok" in which:
+    if "S-OLP-tok" in which or "S-OLP-tok-short" in which:
         from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
         n_ent, n_rel, d, B, N, L, vt_e, vt_r = 2_500_000, 100_000, 256, 4096, 8192, 10, 200_000, 50_000
 
@@ -168,6 +168,8 @@ def main():
                                          sp_subj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)),
                                          pos_row=t(pr), pos_col=t(pc), cand_ids=t(rng.choice(n_ent - 2, N, replace=False).astype(np.int32) + 2)))
         run("S-OLP-tok", step, batches, steps=20, warmup=3)
+        if "S-OLP-tok-short" in which:
+            return
         # the same step on the Adagrad state of a run IN PROGRESS: once a row's accumulator has seen a real gradient, the
         # weight-decay-only update of a step that does not touch the row leaves its bits unchanged and the sweep skips the
         # two stores (okge_misc.hip adagrad_sweep).  Two resident batches touch ~15 % of the token rows; in the line above
