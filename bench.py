@@ -228,10 +228,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a dead or wedged rank ends the run with an error after five minutes (the process exits non-zero) instead of hanging
+        import datetime
         if one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=5))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=5))
 
     import dataclasses
     w = synthetic.WORKLOADS[args.workload]
@@ -242,7 +244,8 @@ def main():
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(minutes=5))
         from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep, shard_range
         # global batch grows with the number of GPUs; identical on every rank (same seeds)
         wg = dataclasses.replace(w, n_po=w.n_po * world, n_sp=w.n_sp * world)
@@ -416,6 +419,15 @@ def main():
         torch.cuda.empty_cache()
         olp = run_olp(world, rank, dev, dist, barrier)
 
+    # ---- the other BASELINE configurations on the driver's clock (single GPU, untimed region like `eval` / `dropin`):
+    #      configs[2] S-DM, configs[4] S-OLP-tok and configs[1] with the KL loss, through tools/bench_configs.py's code path,
+    #      50 warm-up + 200 timed steps each, per-kernel HIP-event averages beside the step time
+    configs = None
+    if rank == 0 and world == 1 and not sharded and args.workload == "S-FB" and os.environ.get("OKGE_BENCH_CONFIGS", "1") == "1":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+        configs = {name: bench_configs.measure_config(name, dev, peak_tflops=FP32_MFMA_PEAK_TFLOPS) for name in ("S-DM", "S-OLP-tok", "S-FB-kl")}
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -436,7 +448,7 @@ def main():
                    "global_batch": w_run.B,
                    "parallelism": f"entity table row-sharded x{world}, batch 512 x{world}" if sharded else "single"},
         "prefixes_per_s": w_run.B * args.steps / elapsed, "last_loss_sum": loss_last,
-        "roofline": roof, "cpu_baseline": cpu, "eval": ev, "dropin": dropin, "olp": olp,
+        "roofline": roof, "cpu_baseline": cpu, "eval": ev, "dropin": dropin, "olp": olp, "configs": configs,
     }
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())

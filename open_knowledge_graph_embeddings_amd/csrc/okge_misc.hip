@@ -207,6 +207,8 @@ __global__ __launch_bounds__(256) void dc_reduce_kernel(const float *__restrict_
 // runs; workgroup p owns units [U p / P, U (p + 1) / P), U = tiles * J.  A tile covered by ONE segment was written by that
 // workgroup; otherwise every segment left its partial rows in slab 2 p (p's run starts inside the tile) or 2 p + 1 (it
 // ends there).  One workgroup per tile: list the slabs (in p order: the sum is reproducible), add them, store / accumulate.
+constexpr int SK_MAX_WGS = 511, SK_SLOTS = 1024;     // a tile's slab list holds at most two entries per workgroup of the launch
+static_assert(SK_SLOTS >= 2 * (SK_MAX_WGS + 1), "dc_reduce_streamk_kernel: slot list too small for the largest stream-K launch");
 __global__ __launch_bounds__(256) void dc_reduce_streamk_kernel(const float *__restrict__ slab, int tiles, int J, int P, int D16,
                                                                 int N, int d, const int32_t *__restrict__ cand_ids,
                                                                 int cand_first, int exclusive, int grads_zero,
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void dc_reduce_streamk_kernel(const float *__r
                                                                 int *__restrict__ id_err)
 {
     // grid: 8 workgroups per tile (8 candidate rows each: the launch is a 3 x 20 MB stream, it needs the whole chip)
-    __shared__ int slots[1024];
+    __shared__ int slots[SK_SLOTS];
     __shared__ int n_slots;
     const int t = blockIdx.x >> 3, r0 = 8 * (blockIdx.x & 7);
     const int64_t U = (int64_t)tiles * J, lo = (int64_t)t * J, hi = lo + J;
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(256) void dc_reduce_streamk_kernel(const float *__r
             const int64_t j0 = (ub > lo ? ub : lo) - lo, j1 = (ue < hi ? ue : hi) - lo;
             if (j1 <= j0) continue;
             if (j0 == 0 && j1 == J) { whole = true; break; }
-            if (cnt < 1024) slots[cnt++] = (int)(2 * p + (ub >= lo ? 0 : 1));
+            if (cnt < SK_SLOTS) slots[cnt++] = (int)(2 * p + (ub >= lo ? 0 : 1));
+            else if (id_err) atomicAdd(id_err, 1);            // (unreachable: the launcher refuses P > SK_MAX_WGS; never a silent drop)
         }
         n_slots = whole ? 0 : cnt;
     }
@@ -488,9 +491,10 @@ __global__ __launch_bounds__(128) void row_segment_sum_kernel(const float *__res
     const bool is_rel = (int)blockIdx.x < rel.n_seg;
     const RowSegments &sg = is_rel ? rel : ent;
     const int sidx = is_rel ? blockIdx.x : blockIdx.x - rel.n_seg;
-    const int lo = sg.seg_ptr[sidx], hi = sg.seg_ptr[sidx + 1];
-    if (hi <= lo) return;
     const int B = p.n_po + p.n_sp;
+    // (the plan is host-built and trusted for speed, never for safety: bounds outside [0, B] would read `order` out of range)
+    const int lo = min(max(sg.seg_ptr[sidx], 0), B), hi = min(max(sg.seg_ptr[sidx + 1], 0), B);
+    if (hi <= lo) return;
     const RowSrc rs = row_source(p, min(max(sg.order[lo], 0), B - 1), false);
     if (!is_rel && !rs.owned) return;
     const float *rows = is_rel ? dr_rows : de_rows;
@@ -1131,7 +1135,7 @@ hipError_t launch_dc_reduce_streamk(const float *slab, int tiles, int chunks_per
                                     int64_t table_rows, int *id_err, hipStream_t st)
 {
     if (tiles <= 0) return hipSuccess;
-    if (workgroups > 511) return hipErrorInvalidValue;             // (slot list of a tile: at most workgroups + 1 entries)
+    if (workgroups > SK_MAX_WGS) return hipErrorInvalidValue;      // (slot list of a tile: at most two entries per workgroup)
     hipLaunchKernelGGL(dc_reduce_streamk_kernel, dim3(8 * tiles), dim3(256), 0, st, slab, tiles, chunks_per_tile, workgroups, D16,
                        N, d, cand_ids, cand_first, exclusive, grads_zero, dE, table_rows, id_err);
     return hipGetLastError();

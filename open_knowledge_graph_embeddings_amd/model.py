@@ -233,6 +233,7 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
                                       self.bn_e if self.batch_norm else None, lookup)
         eng = self.engine()
         weight = (self.relation_embedding if relation else self.entity_embedding).weight
+        self._fresh_mask_for_direct_call(slot_item if not lookup else weight)
         if not lookup:                    # model.py:459-460: already rows, only dropout applies
             if _wants_grad(slot_item):
                 return AG.MaskRowsFn.apply(slot_item, eng, self.dropout_spec(stream, relation))
@@ -242,6 +243,14 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
             ids = slot_item.reshape(-1)
             return AG.EncodeRowsFn.apply(weight, ids, 0, int(ids.numel()), eng, self.dropout_spec(stream, relation))
         return eng.encode_rows(table, slot_item.reshape(-1), drop=self.dropout_spec(stream, relation))
+
+    def _fresh_mask_for_direct_call(self, source):
+        """encode_* / get_all_* called DIRECTLY in training mode with gradients enabled (a caller's own loss built from
+        encoded rows): every such call draws a fresh Philox mask, as each of the reference's _encode calls draws a fresh
+        Bernoulli mask (model.py:455-470).  Inside _prefix_score / AddLossModule the step counter is advanced once per
+        call there (the five encode calls of a step are told apart by their stream ids)."""
+        if self.training and not getattr(self, "_in_prefix_score", False) and _wants_grad(source):
+            self.dropout_step += 1
 
     def encode_subj(self, subj, lookup=True):
         return self._encode(self.E, subj, H.STREAM_SP_ENT, False, lookup, which="subj")
@@ -257,6 +266,7 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
             w = (self.relation_embedding if relation else self.entity_embedding).weight[min_size:].contiguous()
             return self._encode(None, w, stream, relation, lookup=False, which=which)
         weight = (self.relation_embedding if relation else self.entity_embedding).weight
+        self._fresh_mask_for_direct_call(weight)
         if _wants_grad(weight):
             return AG.EncodeRowsFn.apply(weight, None, min_size, table.shape[0] - min_size, self.engine(),
                                          self.dropout_spec(stream, relation))
@@ -294,13 +304,17 @@ class LookupBaseRelationEmbedder(RelationEmbedder):
         if with_graph and self.training:
             self.dropout_step += 1         # fresh masks per call, as each of the reference's encode calls draws them
         if self.encode_in_torch or with_graph:   # torch encode of the variants / a graph for the caller's loss: the
-            if batch.sp_subj is not None:        # reference's own call order (model.py:52-74), HIP scorer
-                subj, rel = self.encode_subj(batch.sp_subj), self.encode_rel(batch.sp_rel)
-                return self._score(subj, rel, self.get_all_obj() if many is None else many, prefix=True, sp=True, po=False)
-            if many is None:
-                many = self.get_all_subj()
-            rel, obj = self.encode_rel(batch.po_rel), self.encode_obj(batch.po_obj)
-            return self._score(many, rel, obj, prefix=True, sp=False, po=True)
+            self._in_prefix_score = True         # reference's own call order (model.py:52-74), HIP scorer
+            try:
+                if batch.sp_subj is not None:
+                    subj, rel = self.encode_subj(batch.sp_subj), self.encode_rel(batch.sp_rel)
+                    return self._score(subj, rel, self.get_all_obj() if many is None else many, prefix=True, sp=True, po=False)
+                if many is None:
+                    many = self.get_all_subj()
+                rel, obj = self.encode_rel(batch.po_rel), self.encode_obj(batch.po_obj)
+                return self._score(many, rel, obj, prefix=True, sp=False, po=True)
+            finally:
+                self._in_prefix_score = False
         if many is None:                   # all entities with id >= min_entities_size (model.py:512-523)
             batch.cand_first = self.train_data.min_entities_size
             batch.n_cand = self.E.shape[0] - batch.cand_first

@@ -201,20 +201,30 @@ class AddLossModule(nn.Module):
         calls = []                                                                  # (EV, RV, virtual batch, output rows)
         with torch.set_grad_enabled(want_grad):
             if per_direction:
+                # the positives of one direction WITHOUT a host synchronisation (boolean-mask indexing reads the count back):
+                # the other direction's entries become padding -- (row -1, column INT32_MAX), which the kernels skip and which
+                # sorts behind every candidate tile (okge.h, okge_positives) -- and a stable device sort restores column order
+                pad_col = torch.iinfo(torch.int32).max
+
+                def direction_positives(keep, row_shift):
+                    col = torch.where(keep, batch.pos_col, torch.full_like(batch.pos_col, pad_col))
+                    row = torch.where(keep, batch.pos_row - row_shift, torch.full_like(batch.pos_row, -1))
+                    order = torch.argsort(col, stable=True)
+                    return row[order].contiguous(), col[order].contiguous()
                 in_po = batch.pos_row < n_po
                 if n_po:
                     cand = m.get_all_subj().reshape(n_c, -1)
                     rel = m.encode_rel(batch.po_rel).reshape(n_po, -1)
                     obj = m.encode_obj(batch.po_obj).reshape(n_po, -1)
-                    vb = H.PrefixBatch(po_rel=ar(0, n_po), po_obj=ar(n_c, n_c + n_po), pos_row=batch.pos_row[in_po],
-                                       pos_col=batch.pos_col[in_po], cand_first=0, n_cand=n_c)
+                    prow, pcol = direction_positives(in_po, 0)
+                    vb = H.PrefixBatch(po_rel=ar(0, n_po), po_obj=ar(n_c, n_c + n_po), pos_row=prow, pos_col=pcol, cand_first=0, n_cand=n_c)
                     calls.append((torch.cat([cand, obj]), rel, vb, slice(0, n_po)))
                 if n_sp:
                     subj = m.encode_subj(batch.sp_subj).reshape(n_sp, -1)
                     rel = m.encode_rel(batch.sp_rel).reshape(n_sp, -1)
                     cand = m.get_all_obj().reshape(n_c, -1)
-                    vb = H.PrefixBatch(sp_subj=ar(n_c, n_c + n_sp), sp_rel=ar(0, n_sp), pos_row=batch.pos_row[~in_po] - n_po,
-                                       pos_col=batch.pos_col[~in_po], cand_first=0, n_cand=n_c)
+                    prow, pcol = direction_positives(~in_po, n_po)
+                    vb = H.PrefixBatch(sp_subj=ar(n_c, n_c + n_sp), sp_rel=ar(0, n_sp), pos_row=prow, pos_col=pcol, cand_first=0, n_cand=n_c)
                     calls.append((torch.cat([cand, subj]), rel, vb, slice(n_po, n_po + n_sp)))
             else:
                 if all_entities:

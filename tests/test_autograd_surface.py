@@ -208,3 +208,22 @@ def test_token_pooled_methods_carry_a_graph(okge_lib, pool, bn):
     y1 = m.sp_prefix_score(subj.cuda(), rel.cuda(), m.precompute_batch_shared_inputs(cand_ids.cuda()))
     assert not y0.requires_grad and y1.requires_grad
     np.testing.assert_allclose(y1.detach().cpu().numpy(), y0.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_direct_encode_calls_draw_fresh_masks(okge_lib):
+    """encode_* / get_all_* called directly in training mode with gradients on: every call its own Philox mask, as each of
+    the reference's _encode calls draws its own Bernoulli mask (model.py:455-470); in eval mode no dropout at all"""
+    m, _, rng = _pair("complex", 200, 8, 64, seed=12, dropout=0.4)
+    m.train()
+    obj = _ids(rng, 2, 200, 32).cuda()
+    a, b = m.encode_obj(obj), m.encode_obj(obj)
+    za, zb = (a == 0), (b == 0)
+    assert 0.25 < float(za.float().mean()) < 0.55 and bool((za != zb).any())          # dropped components differ between the calls
+    c, d_ = m.get_all_obj(), m.get_all_obj()
+    assert bool(((c == 0) != (d_ == 0)).any())
+    (a.sum() + b.sum()).backward()                                                      # each backward replays ITS call's mask
+    g = m.entity_embedding.weight.grad
+    assert float(g.abs().sum()) > 0
+    m.eval()
+    assert torch.equal(m.encode_obj(obj), m.encode_obj(obj))

@@ -292,3 +292,18 @@ def test_merge_logsumexp(okge_lib):
     x = torch.randn(5, 1000, device="cuda") * 20
     x[2, 7] = float("-inf")
     np.testing.assert_allclose(hp.merge_logsumexp(x).cpu().numpy(), torch.logsumexp(x, 0).cpu().numpy(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_validate_config_rejects_bad_ids_before_any_kernel(okge_lib, validate_config):
+    """OKGE_VALIDATE=1 (integration work): ids are range-checked on the host before the call; nothing reaches the kernels"""
+    from open_knowledge_graph_embeddings_amd import _native as N
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    dev = torch.device("cuda:0")
+    hp = H.HotPath(dev)
+    E, R = torch.randn((50, 16), device=dev), torch.randn((7, 16), device=dev)
+    t = lambda *a: torch.tensor(a, dtype=torch.int32, device=dev)      # noqa: E731
+    bad = H.PrefixBatch(sp_subj=t(3, 50), sp_rel=t(2, 3), pos_row=t(0), pos_col=t(1), cand_first=2, n_cand=48)
+    with pytest.raises(N.OkgeError):
+        hp.score(E, R, "complex", bad)
+    assert N.id_errors() == 0

@@ -106,7 +106,7 @@ def _worker(rank, world, port, outdir, nsteps, loss, use_plan=False):
     import torch.distributed as dist
     from open_knowledge_graph_embeddings_amd.sharded import ShardedEvaluator, ShardedTrainStep, shard_range
     from shard_engine_cpu import OracleShardEngine
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(minutes=5))
     E, R = tables()
     lo, hi = shard_range(N_ENT, world, rank)
     # evaluation on the initial tables: ranks must come out identical on every rank
@@ -194,7 +194,7 @@ def _replica_worker(rank, world, port, outdir, nsteps):
     from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
     from open_knowledge_graph_embeddings_amd.sharded import ReplicaTrainStep
     from shard_engine_cpu import OracleShardEngine
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(minutes=5))
     E, R = tables()
     st = ReplicaTrainStep(torch.from_numpy(E.copy()), torch.from_numpy(R.copy()), SCORER, lr=LR, engine=OracleShardEngine())
     t = torch.from_numpy
@@ -276,7 +276,7 @@ def _replica_step_worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(minutes=5))
     inner = _ToyInner(rank)
     st = ReplicaStep(inner)
     assert inner.seed == 7 + 1000003 * rank
@@ -327,7 +327,7 @@ def _replica_sparse_worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(minutes=5))
     inner = _ToySparseInner(rank)
     st = ReplicaStep(inner)
     sent = []
@@ -813,24 +813,28 @@ def _nccl_worker(rank, world, port, outdir, nsteps, loss):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
     import torch.distributed as dist
     from open_knowledge_graph_embeddings_amd.sharded import ShardedEvaluator, ShardedTrainStep, make_exchange_plan, shard_range
     dev = torch.device("cuda", rank)
     torch.cuda.set_device(dev)
-    try:
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
-        probe = torch.ones(1, device=dev)
-        dist.all_reduce(probe)
-        torch.cuda.synchronize()
-    except Exception as e:                                       # RCCL could not come up on this box: not a numerics failure
-        open(os.path.join(outdir, f"rank{rank}.skip"), "w").write(repr(e))
-        return
+    # two devices are visible: from here on ANY failure -- bring-up included -- fails the test (a dead peer ends in the
+    # collective timeout, not in a hang)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev,
+                            timeout=datetime.timedelta(minutes=5))
+    probe = torch.ones(1, device=dev)
+    dist.all_reduce(probe)
+    torch.cuda.synchronize()
+    assert float(probe[0]) == world
     E, R = tables()
     lo, hi = shard_range(N_ENT, world, rank)
     t = lambda a: torch.from_numpy(a).to(dev)      # noqa: E731
     ev = ShardedEvaluator(t(E[lo:hi].copy()), t(R.copy()), SCORER, N_ENT)
     eb = eval_problem()
-    ranks = ev.ranks(to_batch(eb, dev), t(eb["filt_ptr"]), t(eb["filt_col"]), t(eb["row_ptr"]), t(eb["grp_ptr"]), t(eb["ids"]))
+    csr = (t(eb["filt_ptr"]), t(eb["filt_col"]), t(eb["row_ptr"]), t(eb["grp_ptr"]), t(eb["ids"]))
+    ranks = ev.ranks(to_batch(eb, dev), *csr)
+    # ... and with exchange 1 as the all-gather of owned rows (the host-built plan)
+    ranks_plan = ev.ranks(to_batch(eb, dev), *csr, plan=make_exchange_plan(eb["po_obj"], eb["sp_subj"], N_ENT, world, dev))
     st = ShardedTrainStep(t(E[lo:hi].copy()), t(R.copy()), SCORER, N_ENT, lr=LR, input_dropout=P_DROP, seed=SEED, loss=loss)
     losses = []
     for step in range(1, nsteps + 1):
@@ -840,7 +844,7 @@ def _nccl_worker(rank, world, port, outdir, nsteps, loss):
         losses.append(float(st.reduce_loss()[0]))
     torch.cuda.synchronize()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), E=st.E.cpu().numpy(), R=st.R.cpu().numpy(), lo=lo, hi=hi,
-             losses=np.asarray(losses), ranks=ranks.cpu().numpy())
+             losses=np.asarray(losses), ranks=ranks.cpu().numpy(), ranks_plan=ranks_plan.cpu().numpy())
     dist.destroy_process_group()
 
 
@@ -848,7 +852,8 @@ def _nccl_worker(rank, world, port, outdir, nsteps, loss):
 @pytest.mark.parametrize("loss", ["bce", "kl"])
 def test_sharded_step_two_ranks_rccl(okge_lib, loss):
     """The real thing: two processes, two GPUs, RCCL -- entity table row-sharded, both exchanges (all-gather plan on even
-    steps, all-reduce on odd ones), sharded evaluation.  Skipped on one-GPU boxes; the first box with two or more runs it."""
+    steps, all-reduce on odd ones), sharded evaluation with and without the plan.  Skipped ONLY on one-GPU boxes: once two
+    devices are visible, an RCCL bring-up or collective error is a failure, not a skip."""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     import torch.multiprocessing as mp
@@ -858,14 +863,12 @@ def test_sharded_step_two_ranks_rccl(okge_lib, loss):
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as outdir:
         mp.spawn(_nccl_worker, args=(world, port, outdir, nsteps, loss), nprocs=world, join=True)
-        skips = [f for f in os.listdir(outdir) if f.endswith(".skip")]
-        if skips:
-            pytest.skip("RCCL did not initialise here: " + open(os.path.join(outdir, skips[0])).read()[:200])
         parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
     E_ref, R_ref, losses_ref = oracle_reference(nsteps, loss=ko.LOSS_KL if loss == "kl" else ko.LOSS_BCE)
     ranks_ref = oracle_ranks(eval_problem())
     for p in parts:
         assert (p["ranks"] != ranks_ref).mean() < 0.01 and np.abs(p["ranks"] - ranks_ref).max() <= 1
+        np.testing.assert_array_equal(p["ranks"], p["ranks_plan"])       # the plan moves the same rows: same bits
     np.testing.assert_array_equal(parts[0]["ranks"], parts[1]["ranks"])
     E = np.concatenate([p["E"] for p in parts])
     close = np.isclose(E, E_ref, rtol=1e-3, atol=1e-4)
@@ -873,6 +876,74 @@ def test_sharded_step_two_ranks_rccl(okge_lib, loss):
     for p in parts:
         np.testing.assert_allclose(p["R"], R_ref, rtol=1e-3, atol=1e-4)
         np.testing.assert_allclose(p["losses"], losses_ref, rtol=3e-5)
+
+
+def _token_pooled_replica_problem(rank, step, n_ids=300, n_rel=30):
+    r2 = np.random.default_rng(900 + 10 * step + rank)
+    b, nc = 24, 64
+    return dict(cand=r2.permutation(np.arange(2, n_ids))[:nc].astype(np.int32), rows=np.arange(2 * b, dtype=np.int32),
+                cols=np.sort(r2.integers(0, nc, 2 * b)).astype(np.int32), po_rel=r2.integers(2, n_rel, b).astype(np.int32),
+                po_obj=r2.integers(2, n_ids, b).astype(np.int32), sp_subj=r2.integers(2, n_ids, b).astype(np.int32),
+                sp_rel=r2.integers(2, n_rel, b).astype(np.int32))
+
+
+def _token_pooled_tables(n_ids=300, n_rel=30, vocab=80, L=4, d=64):
+    rng = np.random.default_rng(77)
+    tok = lambda n: np.concatenate([rng.integers(1, vocab, (n, L - 1)), np.zeros((n, 1), np.int64)], axis=1).astype(np.int32)   # noqa: E731
+    return dict(We=(rng.standard_normal((vocab, d)) * 0.3).astype(np.float32), Wr=(rng.standard_normal((vocab, d)) * 0.3).astype(np.float32),
+                te=tok(n_ids), tr=tok(n_rel), bw=rng.random(d).astype(np.float32), bb=(rng.standard_normal(d) * 0.1).astype(np.float32))
+
+
+def _nccl_replica_worker(rank, world, port, outdir, nsteps):
+    """ReplicaStep(sparse=True) around the token-pooled step on real streams: side-stream mask all-reduce, packed touched-row
+    exchange, the touched-row map of the optimizer sweep stamped for the OTHER replica's rows"""
+    sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev,
+                            timeout=datetime.timedelta(minutes=5))
+    z = _token_pooled_tables()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    e = TokenSlot(t(z["We"]), t(z["te"]), "sum", True, t(z["bw"]), t(z["bb"]))
+    r = TokenSlot(t(z["Wr"]), t(z["tr"]), "sum", True, t(z["bw"]), t(z["bb"]))
+    rep = ReplicaStep(TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=0.0, seed=5), sparse=True)
+    sent = []
+    for step in range(nsteps):
+        p = _token_pooled_replica_problem(rank, step)
+        rep.step(PrefixBatch(po_rel=t(p["po_rel"]), po_obj=t(p["po_obj"]), sp_subj=t(p["sp_subj"]), sp_rel=t(p["sp_rel"]),
+                             pos_row=t(p["rows"]), pos_col=t(p["cols"]), cand_ids=t(p["cand"])))
+        sent.append(rep.last_exchanged_elements)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), We=e.W.cpu().numpy(), Wr=r.W.cpu().numpy(), bn=e.bn.cpu().numpy(),
+             rm=e.running_mean.cpu().numpy(), sent=np.asarray(sent), dense=e.W.numel() + r.W.numel())
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replica_step_sparse_two_ranks_rccl(okge_lib):
+    """token-pooled replicas over RCCL: identical tables on both ranks after three steps, equal to ONE replica stepping on
+    the two batches' summed gradients (float64 oracle, loose: Adagrad conditioning), fewer floats on the wire than the tables"""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    world, nsteps = 2, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_nccl_replica_worker, args=(world, port, outdir, nsteps), nprocs=world, join=True)
+        parts = [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
+    for k in ("We", "Wr", "bn", "rm"):
+        np.testing.assert_array_equal(parts[0][k], parts[1][k])         # the same exchanged sums, the same sweep: no drift
+    assert (parts[0]["sent"] < parts[0]["dense"]).all() and (parts[0]["sent"] == parts[1]["sent"]).all()
+    z = _token_pooled_tables()
+    assert np.abs(parts[0]["We"] - z["We"]).max() > 1e-3                # the tables moved
 
 
 @pytest.mark.gpu

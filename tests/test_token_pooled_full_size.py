@@ -67,6 +67,28 @@ def _oracle(z):
     return out
 
 
+def _reference_fp32_scores(z):
+    """the scores as the REFERENCE'S OWN fp32 op sequence produces them (model.py:762-786 + :205-216): sum pooling, training-mode
+    BatchNorm1d, dropout (this build's Philox masks), then the literal four matrix products -- NumPy in float32"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    d = D
+    km = lambda stream, n: ko.dropout_keep_mask(SEED, stream, 1, n, d, P_DROP)           # noqa: E731
+    scale = np.float32(1.0 / (1.0 - P_DROP))
+
+    def enc(W, tokens, ids, w_, b_, mask):
+        x, _ = ko.token_pool(W, tokens, ids, "sum")
+        x, _ = ko.batchnorm_train(x, w_, b_)
+        return (x * (mask.astype(np.float32) * scale)).astype(np.float32)
+    C = enc(z["We"], z["ent_tokens"], z["cand"], z["bn_e_w"], z["bn_e_b"], km(H.STREAM_CAND, N_CAND))
+    r_po = enc(z["Wr"], z["rel_tokens"], z["po_rel"], z["bn_r_w"], z["bn_r_b"], km(H.STREAM_PO_REL, B // 2))
+    e_po = enc(z["We"], z["ent_tokens"], z["po_obj"], z["bn_e_w"], z["bn_e_b"], km(H.STREAM_PO_ENT, B // 2))
+    e_sp = enc(z["We"], z["ent_tokens"], z["sp_subj"], z["bn_e_w"], z["bn_e_b"], km(H.STREAM_SP_ENT, B // 2))
+    r_sp = enc(z["Wr"], z["rel_tokens"], z["sp_rel"], z["bn_r_w"], z["bn_r_b"], km(H.STREAM_SP_REL, B // 2))
+    X = np.concatenate([ko.score_prefix_4mm(ko.COMPLEX, ko.DIR_PO, e_po, r_po, C), ko.score_prefix_4mm(ko.COMPLEX, ko.DIR_SP, e_sp, r_sp, C)])
+    assert X.dtype == np.float32
+    return X
+
+
 def _step(z):
     from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()           # noqa: E731
@@ -82,16 +104,34 @@ def _batch(z):
                        pos_row=t(z["pos_row"]), pos_col=t(z["pos_col"]), cand_ids=t(z["cand"]))
 
 
-def _check(st, ref, loss, scores=None):
+def _check(st, ref, loss, scores=None, ref32=None):
     assert abs(float(loss[0]) - ref["loss"]) <= 3e-5 * abs(ref["loss"])
     if scores is not None:
         x = scores.cpu().numpy()
         assert np.abs(ref["outputs"]).max() > 2.0                       # scores well off zero: the sigmoid is exercised
-        # north_star bound 1e-4 -- plus 2e-6 relative: batch-normed rows of 256 columns give scores up to |x| ~ 165, where
-        # one fp32 ulp is already 1.5e-5 and a 256-term sum cannot be closer than a few ulps to the float64 value
-        np.testing.assert_allclose(x, ref["outputs"], rtol=2e-6, atol=1e-4)
-        small = np.abs(ref["outputs"]) <= 30.0
-        assert small.mean() > 0.9 and np.abs(x - ref["outputs"])[small].max() <= 1e-4       # the bound itself where |x| <= 30
+        # north_star bound: 1e-4 against the reference's fp32 scores.  Batch-normed rows of 256 columns give scores up to
+        # |x| ~ 165, where one fp32 ulp is 1.5e-5: `ref32` is the REFERENCE'S OWN op sequence (pool, batch-norm, dropout, the
+        # literal four matrix products) in float32 (NumPy), the yardstick in place of a free relative term.  Measured
+        # (tools/cfg5_error_table.py, distance to float64 by |x| band: this build max / rms | ref32 max / rms):
+        #     (0, 30]    6.8e-5 / 5e-6  | 6.2e-5 / 4e-6        (60, 100]  1.01e-4 / 2.2e-5 | 8.4e-5 / 1.5e-5
+        #     (30, 60]   7.9e-5 / 1.2e-5 | 7.0e-5 / 8.9e-6      (100, oo)  1.99e-4 / 3.4e-5 | 7.8e-5 / 2.4e-5
+        # i.e. the 1e-4 bound holds for every score up to |x| = 60 and for all but 12 of 33 554 432 overall (10 of them differ
+        # by more than 1e-4 from ref32 itself, all at |x| > 130); this build's rms error is 1.2-1.5x the fp32 reference's: the
+        # MFMA product is ONE k-ordered chain of 256 fmas per score, a blocked sgemm keeps several shorter partial sums.
+        err = np.abs(x - ref["outputs"])
+        mag = np.abs(ref["outputs"])
+        assert (mag <= 60.0).mean() > 0.99 and err[mag <= 60.0].max() <= 1e-4      # the bound itself where |x| <= 60
+        assert err.max() <= 3e-4                                                    # nowhere further than ~15 ulps at |x| ~ 165
+        assert int((err > 1e-4).sum()) <= 32                                        # observed: 12
+        if ref32 is not None:
+            err32 = np.abs(ref32.astype(np.float64) - ref["outputs"])
+            for lo_, hi_ in ((0.0, 30.0), (30.0, 60.0), (60.0, 100.0), (100.0, np.inf)):
+                band = (mag > lo_) & (mag <= hi_)
+                # the largest error of a band within 3x the fp32 reference's (observed <= 2.6x), the rms within 1.6x (<= 1.5x)
+                assert err[band].max() <= max(1e-4, 3.0 * err32[band].max()), (lo_, err[band].max(), err32[band].max())
+                assert np.sqrt((err[band] ** 2).mean()) <= 1.6 * np.sqrt((err32[band] ** 2).mean()) + 1e-7, lo_
+            direct = np.abs(x - ref32)
+            assert int((direct > 1e-4).sum()) <= 32 and direct.max() <= 3e-4        # observed: 10 of 33.5 M, max 2.1e-4
     e, r = st.entity, st.relation
     for mine, want in ((e.dW, ref["dWe"]), (r.dW, ref["dWr"])):
         got = mine.cpu().numpy()
@@ -120,7 +160,7 @@ def test_token_pooled_step_at_config5_size(okge_lib, problem, reference):
     scores = torch.empty((B, N_CAND), device="cuda:0")
     loss = st.forward_backward(_batch(problem), scores=scores)
     torch.cuda.synchronize()
-    _check(st, reference, loss, scores)
+    _check(st, reference, loss, scores, ref32=_reference_fp32_scores(problem))
     # the optimiser sweep at this size: dense Adagrad over both token tables and the batch-norm parameters
     We, sums = problem["We"].astype(np.float64), np.zeros((V_ENT, D))
     ko.adagrad_step(We, reference["dWe"], sums, 0.1)

@@ -230,7 +230,9 @@ def test_hip_g11_trajectory_and_mrr(okge_lib):
     fptr = np.concatenate([[0], np.cumsum(np.bincount(f[:, 0], minlength=512))]).astype(np.int64)
     ranks = hp.filtered_ranks(x.contiguous(), _dev(fptr), _dev(f[:, 1].astype(np.int32)), _dev(z["eval_row_ptr"]),
                               _dev(z["eval_grp_ptr"]), _dev(z["eval_ids"])).cpu().numpy()
-    compare_ranks(ranks, z["eval_ranks"], 0.10, "hip g11 (own 30-step trajectory)", max_delta=8)
+    # observed: 46 of 723 groups (6.4 %) move, none by more than 4 places of ~6400 (30 steps of another summation order;
+    # on IDENTICAL tables -- the next test and G13 -- it is 1 of 723 by one place); bound = observed + 50 %
+    compare_ranks(ranks, z["eval_ranks"], 0.096, "hip g11 (own 30-step trajectory)", max_delta=4)
     m, _ = ko.metrics_from_ranks(ranks, z["eval_row_ptr"])
     assert abs(m["mrr"] - float(z["eval_m_mrr"])) < 1e-3
     for k in ("h1", "h3", "h10", "h50"):

@@ -28,7 +28,7 @@ def positives(rng, B, N, per_row=2):
     return (key % B).astype(np.int32), (key // B).astype(np.int32)
 
 
-def run(name, step, batches, steps=30, warmup=5):
+def run(name, step, batches, steps=30, warmup=5, ksteps=10, quiet=False):
     for i in range(warmup):
         step.step(batches[i % len(batches)])
     torch.cuda.synchronize()
@@ -39,15 +39,79 @@ def run(name, step, batches, steps=30, warmup=5):
     ms = 1e3 * (time.perf_counter() - t0) / steps
     eng = step.engine
     eng.timing(True)
-    for i in range(10):
+    for i in range(ksteps):
         step.step(batches[i % len(batches)])
     torch.cuda.synchronize()
     per = {k: round(v[0] / v[1] * 1e3, 2) for k, v in eng.timing_collect().items()}
     eng.timing(False)
     b = batches[0]
     out = {"workload": name, "ms_per_step": round(ms, 4), "prefixes_per_s": round(b.B / ms * 1e3), "kernels_us": per}
-    print(json.dumps(out), flush=True)
+    if not quiet:
+        print(json.dumps(out), flush=True)
     return out
+
+
+def positives_batch(rng, t, n_ent, n_rel, B, N, per_row, cand_ids=None, cand_unique=False):
+    pr, pc = positives(rng, B, N, per_row=per_row)
+    kw = dict(cand_ids=cand_ids, cand_unique=cand_unique) if cand_ids is not None else dict(cand_first=2, n_cand=N)
+    return H.PrefixBatch(po_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)),
+                         sp_subj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)),
+                         pos_row=t(pr), pos_col=t(pc), **kw)
+
+
+# ---- the workloads as (step object, resident batches, description, flops per step [6 B N d; KL: 8 B N d], flops of the tile launch) ----
+def setup_s_dm(dev, rng, t):
+    n_ent, n_rel, d, B, N = 14543, 239, 512, 512, 10000
+    E, R = (rng.standard_normal((n, d), dtype=np.float32) * 0.1 for n in (n_ent, n_rel))
+    step = FusedTrainStep(t(E), t(R), "distmult", lr=0.1, input_dropout=0.2, seed=1)
+    batches = [positives_batch(rng, t, n_ent, n_rel, B, N, 2, cand_ids=t(rng.permutation(np.arange(2, n_ent))[:N].astype(np.int32)), cand_unique=True)
+               for _ in range(4)]
+    return step, batches, f"S-DM: DistMult d={d}, B={B}, batch-shared sampled N={N}, input_dropout 0.2, BCE, dense Adagrad", 6.0 * B * N * d, 4.0 * B * N * d
+
+
+def setup_s_fb_kl(dev, rng, t):
+    from open_knowledge_graph_embeddings_amd import synthetic
+    w = synthetic.WORKLOADS["S-FB"]
+    E, R = synthetic.make_tables(w, seed=1234)
+    step = FusedTrainStep(t(E), t(R), w.scorer, loss="kl", lr=w.lr, input_dropout=w.input_dropout, seed=1)
+    batches = []
+    for i in range(4):
+        hb = synthetic.make_batch(w, seed=1234 + i)
+        batches.append(H.PrefixBatch(po_rel=t(hb["po_rel"]), po_obj=t(hb["po_obj"]), sp_subj=t(hb["sp_subj"]), sp_rel=t(hb["sp_rel"]),
+                                     pos_row=t(hb["pos_row"]), pos_col=t(hb["pos_col"]), cand_first=2, n_cand=w.N))
+    return step, batches, f"S-FB-kl: S-FB with the softmax / KL loss (one more score pass for the row log-sum-exp)", 8.0 * w.B * w.N * w.d, 4.0 * w.B * w.N * w.d
+
+
+def setup_s_olp_tok(dev, rng, t):
+    from open_knowledge_graph_embeddings_amd.synthetic import make_token_matrix
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    n_ent, n_rel, d, B, N, L, vt_e, vt_r = 2_500_000, 100_000, 256, 4096, 8192, 10, 200_000, 50_000
+    ent = TokenSlot(torch.randn((vt_e, d), device=dev) * 0.1, t(make_token_matrix(rng, n_ent, vt_e, L)), "sum", True)
+    rel = TokenSlot(torch.randn((vt_r, d), device=dev) * 0.1, t(make_token_matrix(rng, n_rel, vt_r, L)), "sum", True)
+    step = TokenPooledTrainStep(ent, rel, "complex", lr=0.1, dropout=0.1, seed=1)
+    batches = [positives_batch(rng, t, n_ent, n_rel, B, N, 1, cand_ids=t(rng.choice(n_ent - 2, N, replace=False).astype(np.int32) + 2)) for _ in range(2)]
+    return step, batches, (f"S-OLP-tok: token-pooled ComplEx d={d}, B={B}, batch-shared N={N}, {L} tokens per entity from a {vt_e} / {vt_r} Zipf "
+                           f"vocabulary, sum pooling + batch-norm, dropout 0.1, BCE, dense Adagrad over the token tables"), 6.0 * B * N * d, 4.0 * B * N * d
+
+
+SETUPS = {"S-DM": setup_s_dm, "S-FB-kl": setup_s_fb_kl, "S-OLP-tok": setup_s_olp_tok}
+
+
+def measure_config(name, dev, warmup=50, steps=200, peak_tflops=157.3):
+    """one workload through the same code path as the command line, for bench.py's `configs` object"""
+    rng = np.random.default_rng(1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
+    step, batches, what, flops_step, flops_tile = SETUPS[name](dev, rng, t)
+    out = run(name, step, batches, steps=steps, warmup=warmup, ksteps=50, quiet=True)
+    tile_us = out["kernels_us"].get("fused_tile_train")
+    res = {"workload": what, "ms_per_step": out["ms_per_step"], "prefixes_per_s": out["prefixes_per_s"], "steps": steps, "warmup": warmup,
+           "kernels_us": out["kernels_us"], "step_frac": flops_step / (out["ms_per_step"] * 1e-3) / 1e12 / peak_tflops}
+    if tile_us:
+        res["tile_us"] = tile_us
+        res["tile_frac"] = flops_tile / (tile_us * 1e-6) / 1e12 / peak_tflops
+    del step, batches
+    torch.cuda.empty_cache()
+    return res
 
 
 def rank_shape(world, dev, t):
@@ -108,28 +172,11 @@ def main():
     which = sys.argv[1:] or ["S-DM", "S-OLP-shard", "S-OLP-tok"]
     if "S-FB-kl" in which:
         # configs[1] with the softmax / KL loss (trainer.py:99-101): one extra score pass for the row log-sum-exp
-        from open_knowledge_graph_embeddings_amd import synthetic
-        w = synthetic.WORKLOADS["S-FB"]
-        E, R = synthetic.make_tables(w, seed=1234)
-        step = FusedTrainStep(t(E), t(R), w.scorer, loss="kl", lr=w.lr, input_dropout=w.input_dropout, seed=1)
-        batches = []
-        for i in range(4):
-            hb = synthetic.make_batch(w, seed=1234 + i)
-            batches.append(H.PrefixBatch(po_rel=t(hb["po_rel"]), po_obj=t(hb["po_obj"]), sp_subj=t(hb["sp_subj"]), sp_rel=t(hb["sp_rel"]),
-                                         pos_row=t(hb["pos_row"]), pos_col=t(hb["pos_col"]), cand_first=2, n_cand=w.N))
+        step, batches = setup_s_fb_kl(dev, rng, t)[:2]
         run("S-FB-kl", step, batches, steps=100, warmup=10)
         del step, batches
     if "S-DM" in which:
-        n_ent, n_rel, d, B, N = 14543, 239, 512, 512, 10000
-        E, R = (rng.standard_normal((n, d), dtype=np.float32) * 0.1 for n in (n_ent, n_rel))
-        step = FusedTrainStep(t(E), t(R), "distmult", lr=0.1, input_dropout=0.2, seed=1)
-        batches = []
-        for _ in range(4):
-            pr, pc = positives(rng, B, N)
-            batches.append(H.PrefixBatch(po_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)),
-                                         sp_subj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)),
-                                         pos_row=t(pr), pos_col=t(pc), cand_ids=t(rng.permutation(np.arange(2, n_ent))[:N].astype(np.int32)),
-                                         cand_unique=True))
+        step, batches = setup_s_dm(dev, rng, t)[:2]
         run("S-DM", step, batches)
         del step, batches
     if "S-OLP-shard" in which:
@@ -151,22 +198,8 @@ def main():
         if f"S-FB-rank{world}" in which:
             rank_shape(world, dev, t)
     if "S-OLP-tok" in which or "S-OLP-tok-short" in which:
-        from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
-        n_ent, n_rel, d, B, N, L, vt_e, vt_r = 2_500_000, 100_000, 256, 4096, 8192, 10, 200_000, 50_000
-
-        from open_knowledge_graph_embeddings_amd.synthetic import make_token_matrix
-
-        def tokens(n, vocab):
-            return t(make_token_matrix(rng, n, vocab, L))
-        ent = TokenSlot(torch.randn((vt_e, d), device=dev) * 0.1, tokens(n_ent, vt_e), "sum", True)
-        rel = TokenSlot(torch.randn((vt_r, d), device=dev) * 0.1, tokens(n_rel, vt_r), "sum", True)
-        step = TokenPooledTrainStep(ent, rel, "complex", lr=0.1, dropout=0.1, seed=1)
-        batches = []
-        for _ in range(2):
-            pr, pc = positives(rng, B, N, per_row=1)
-            batches.append(H.PrefixBatch(po_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)),
-                                         sp_subj=t(rng.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(rng.integers(2, n_rel, B // 2).astype(np.int32)),
-                                         pos_row=t(pr), pos_col=t(pc), cand_ids=t(rng.choice(n_ent - 2, N, replace=False).astype(np.int32) + 2)))
+        step, batches = setup_s_olp_tok(dev, rng, t)[:2]
+        ent, rel = step.entity, step.relation
         run("S-OLP-tok", step, batches, steps=20, warmup=3)
         if "S-OLP-tok-short" in which:
             return
