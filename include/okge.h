@@ -304,6 +304,25 @@ int okge_pool_backward(const okge_token_embedder *e, const int32_t *ids, int32_t
                        const float *raw, const float *d_out, int64_t ld, float *saved, float *dW,
                        float *d_bn_weight, float *d_bn_bias, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- gradients of the plugin methods' scores (a caller's own loss) ----------------------------------------
+ * Backward of sp_prefix_score / po_prefix_score / _score(prefix=True) (model.py:52-77, :198-229, :268-274) for a caller that
+ * holds the dense (b, n) gradient g of the scores (the reference's autograd walks its four / one matrix products backwards):
+ *   q = fold(ent, rel)   sp: [e1 r1 - e2 r2, e2 r1 + e1 r2]   po: [e1 r1 + e2 r2, e2 r1 - e1 r2]   DistMult: e * r
+ *   d_cand [n][d] = g^T . q        dq = g . cand -> d_ent, d_rel [b][d] by the transpose of the fold
+ * ent / rel / cand are the ENCODED rows the forward saw (dropout already applied); any of the three outputs may be NULL.
+ * Both products run on a hand-written exact-fp32 MFMA kernel; the split contraction is reduced in a fixed order
+ * (bit-reproducible).  The fused training path (okge_train_forward_backward) never forms g and does not come through here. */
+size_t okge_prefix_score_backward_workspace_bytes(int32_t b, int32_t n, int32_t d);
+int okge_prefix_score_backward(int32_t scorer, int32_t sp, const float *g, int64_t ld_g, int32_t b, int32_t n, const float *ent,
+                               int64_t ld_ent, const float *rel, int64_t ld_rel, const float *cand, int64_t ld_cand, int32_t d,
+                               float *d_ent, float *d_rel, float *d_cand, void *workspace, size_t workspace_bytes, void *stream);
+/* Backward of okge_encode_rows (torch.nn.Embedding's backward under model.py:455-470): table_grad[id] += sum of the rows of the
+ * positions that named id, each multiplied by its dropout mask (`drop` as given to the forward; NULL: none).  `order` = the
+ * positions sorted by id (stable): every table row is added up by ONE owner in that order -- no float atomics, bit-reproducible.
+ * ids == NULL: position i names row first_id + i.  Row 0 (padding_idx) receives nothing. */
+int okge_scatter_rows(const float *rows, int64_t ld, const int32_t *ids, const int32_t *order, int32_t first_id, int32_t n, int32_t d,
+                      const okge_dropout *drop, float *table_grad, int32_t table_rows, void *stream);
+
 /* Per-triple scores of ENCODED rows, Hadamard form: RelationScorer.triple_score / forward(subj, rel, obj)
  * (model.py:43-50; ComplEx :231-238  sum s1 r1 o1 + s2 r1 o2 + s1 r2 o2 - s2 r2 o1;  DistMult :276  sum s r o).
  * Inference helper: the reference trains through the prefix path only (trainer.py:59-64). */

@@ -2,10 +2,10 @@
 `sp_prefix_score` / `po_prefix_score` called with gradients enabled (a user's own loss on the scores).
 
 The reference gets these gradients from ATen's autograd through its op sequence (openkge/model.py:198-240, :268-278,
-:455-480).  Here the FORWARD stays on the HIP kernels (okge_encode_rows, okge_score_prefixes) and the backward is the
-transposed arithmetic written out: two library GEMMs (`G . C`, `G^T . Q`; torch.mm = rocBLAS -- plain GEMMs, not the fused
-training path) plus the element-wise chain rule of the folded query.  The training path the reference's Trainer uses
-(AddLossModule: fused loss + backward, no (B, N) gradient block) does not come through here.
+:455-480).  Here the forward AND the backward stay on the HIP kernels: okge_encode_rows / okge_score_prefixes forward;
+okge_prefix_score_backward (`G . C`, `G^T . Q` on a hand-written exact-fp32 MFMA GEMM + the transpose of the query fold) and
+okge_scatter_rows (gradient rows summed per table row in sorted order, dropout masks replayed) backward.  The training path the
+reference's Trainer uses (AddLossModule: fused loss + backward, no (B, N) gradient block) does not come through here.
 """
 from __future__ import annotations
 
@@ -48,22 +48,16 @@ class PrefixScoreFn(torch.autograd.Function):
         batch = H.PrefixBatch(sp_subj=ar, sp_rel=ar) if sp else H.PrefixBatch(po_rel=ar, po_obj=ar)
         batch.cand_table, batch.cand_first, batch.n_cand = cand_c, 0, cand_c.shape[0]
         ctx.save_for_backward(ent_c, rel_c, cand_c)
-        ctx.scorer, ctx.sp = scorer, sp
+        ctx.scorer, ctx.sp, ctx.engine = scorer, sp, engine
         return engine.score(ent_c, rel_c, scorer, batch)
 
     @staticmethod
     def backward(ctx, g):
         ent, rel, cand = ctx.saved_tensors
         g = g.contiguous()
-        with torch.enable_grad():
-            e, r = ent.requires_grad_(), rel.requires_grad_()
-            q = fold_query(ctx.scorer, ctx.sp, e, r)
         need_e, need_r, need_c = ctx.needs_input_grad[:3]
-        d_cand = g.t().mm(q.detach()) if need_c else None
-        d_ent = d_rel = None
-        if need_e or need_r:
-            d_ent, d_rel = torch.autograd.grad(q, (e, r), g.mm(cand))
-        return (d_ent if need_e else None), (d_rel if need_r else None), d_cand, None, None, None
+        d_ent, d_rel, d_cand = ctx.engine.prefix_score_backward(ctx.scorer, ctx.sp, g, ent, rel, cand, need_e, need_r, need_c)
+        return d_ent, d_rel, d_cand, None, None, None
 
 
 class EncodeRowsFn(torch.autograd.Function):
@@ -82,15 +76,9 @@ class EncodeRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
         g = g.contiguous()
-        if ctx.drop is not None and ctx.drop.p > 0:
-            ones = torch.ones_like(g)
-            g = g * ctx.engine.encode_rows(ones, None, 0, g.shape[0], ctx.drop)
-        d_table = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
-        if ctx.has_ids:
-            d_table.index_add_(0, ids.reshape(-1).long(), g)
-        else:
-            d_table[ctx.first_id:ctx.first_id + ctx.n] = g
-        d_table[0].zero_()              # nn.Embedding(padding_idx=PAD = 0), model.py:390-391: the pad row gets no gradient
+        d_table = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)     # dense, like the reference's embedding gradients
+        # (row 0 -- nn.Embedding(padding_idx=PAD = 0), model.py:390-391 -- gets no gradient: the kernel skips it)
+        ctx.engine.scatter_rows(g, ids if ctx.has_ids else None, ctx.first_id, d_table, ctx.drop if ctx.drop is not None else H.NO_DROP)
         return d_table, None, None, None, None, None
 
 
@@ -106,6 +94,6 @@ class MaskRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        if ctx.drop is not None and ctx.drop.p > 0:
-            g = g * ctx.engine.encode_rows(torch.ones_like(g), None, 0, g.shape[0], ctx.drop)
+        if ctx.drop is not None and ctx.drop.p > 0:          # the forward's kernel on the gradient rows: the same masks
+            g = ctx.engine.encode_rows(g, None, 0, g.shape[0], ctx.drop)
         return g, None, None

@@ -878,6 +878,45 @@ int okge_encode_rows(const float *table, int32_t table_rows, int32_t d, const in
     return OKGE_OK;
 }
 
+size_t okge_prefix_score_backward_workspace_bytes(int32_t b, int32_t n, int32_t d)
+{
+    return b > 0 && n > 0 && d > 0 ? score_backward_workspace_bytes(b, n, d) : 0;
+}
+
+int okge_prefix_score_backward(int32_t scorer, int32_t sp, const float *g, int64_t ld_g, int32_t b, int32_t n, const float *ent,
+                               int64_t ld_ent, const float *rel, int64_t ld_rel, const float *cand, int64_t ld_cand, int32_t d,
+                               float *d_ent, float *d_rel, float *d_cand, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!g || !ent || !rel || !cand || b <= 0 || n <= 0 || d <= 0 || ld_g < n || ld_ent < d || ld_rel < d || ld_cand < d)
+        return fail(OKGE_ERR_INVALID, "bad prefix_score_backward arguments");
+    if (scorer != OKGE_COMPLEX && scorer != OKGE_DISTMULT) return fail(OKGE_ERR_INVALID, "unknown scorer");
+    if (scorer == OKGE_COMPLEX && (d & 1)) return fail(OKGE_ERR_INVALID, "ComplEx needs an even slot size");
+    if (!d_ent && !d_rel && !d_cand) return OKGE_OK;
+    if (!workspace || workspace_bytes < score_backward_workspace_bytes(b, n, d) || reinterpret_cast<uintptr_t>(workspace) % 16)
+        return fail(OKGE_ERR_WORKSPACE, "workspace too small or unaligned (okge_prefix_score_backward_workspace_bytes)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("score_backward", st);
+    hipError_t e = launch_score_backward(scorer, sp != 0, g, ld_g, b, n, ent, ld_ent, rel, ld_rel, cand, ld_cand, d, d_ent, d_rel, d_cand,
+                                         workspace, st);
+    if (e != hipSuccess) return fail_hip(e, "score_backward");
+    return OKGE_OK;
+}
+
+int okge_scatter_rows(const float *rows, int64_t ld, const int32_t *ids, const int32_t *order, int32_t first_id, int32_t n, int32_t d,
+                      const okge_dropout *drop, float *table_grad, int32_t table_rows, void *stream)
+{
+    if (!rows || !table_grad || n < 0 || d <= 0 || ld < d || table_rows <= 0) return fail(OKGE_ERR_INVALID, "bad scatter_rows arguments");
+    if (!ids && (first_id < 0 || (int64_t)first_id + n > table_rows)) return fail(OKGE_ERR_INVALID, "row range outside the table");
+    if (ids && n > 1 && !order) return fail(OKGE_ERR_INVALID, "scatter_rows with ids needs the positions sorted by id");
+    okge_dropout none;
+    std::memset(&none, 0, sizeof(none));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("scatter_rows", st);
+    hipError_t e = launch_scatter_rows(rows, ld, ids, order, first_id, n, d, to_dev(drop ? *drop : none), table_grad, table_rows, id_err_ptr(), st);
+    if (e != hipSuccess) return fail_hip(e, "scatter_rows");
+    return OKGE_OK;
+}
+
 int okge_score_triples(int32_t scorer, const float *subj, int64_t ld_subj, const float *rel, int64_t ld_rel,
                        const float *obj, int64_t ld_obj, int32_t n, int32_t d, float *out, void *stream)
 {

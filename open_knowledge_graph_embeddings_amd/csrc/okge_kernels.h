@@ -132,6 +132,13 @@ hipError_t launch_clip_coef(const float *g0, int64_t n0, const float *g1, int64_
                             int n_partial, float *coef_dev, double *norm_dev, hipStream_t st);
 // log-sum-exp over `world` per-shard row log-sum-exps: out[b] = log sum_r exp(parts[r][b])  (sharded KL loss)
 hipError_t launch_merge_lse(const float *parts, int world, int B, float *out, hipStream_t st);
+// backward of the prefix scores from a dense (b, n) gradient block, and the scatter of encoded-row gradients (okge_gemm.hip)
+size_t score_backward_workspace_bytes(int b, int n, int d);
+hipError_t launch_score_backward(int scorer, int sp, const float *G, int64_t ld_g, int b, int n, const float *ent, int64_t ld_ent,
+                                 const float *rel, int64_t ld_rel, const float *cand, int64_t ld_cand, int d, float *d_ent,
+                                 float *d_rel, float *d_cand, void *workspace, hipStream_t st);
+hipError_t launch_scatter_rows(const float *rows, int64_t ld, const int32_t *ids, const int32_t *order, int first_id, int n, int d,
+                               const DropDev &drop, float *table, int64_t table_rows, int *id_err, hipStream_t st);
 // error text for okge_last_error(), shared by the translation units of the C ABI (defined in okge_api.hip)
 int report_error(int code, const std::string &msg);
 

@@ -407,6 +407,35 @@ class HotPath:
                 "okge_encode_rows")
         return out
 
+    def prefix_score_backward(self, scorer, sp, g, ent, rel, cand, need_ent=True, need_rel=True, need_cand=True):
+        """(d_ent, d_rel, d_cand) of scores = fold(ent, rel) . cand^T from the dense (b, n) gradient g (okge_prefix_score_backward)"""
+        b, n = g.shape
+        d = cand.shape[1]
+        need = int(self.lib.okge_prefix_score_backward_workspace_bytes(b, n, d))
+        if getattr(self, "_sb_ws", None) is None or self._sb_ws.numel() < need:
+            self._sb_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = [torch.empty((b, d), dtype=torch.float32, device=self.device) if need_ent else None,
+               torch.empty((b, d), dtype=torch.float32, device=self.device) if need_rel else None,
+               torch.empty((n, d), dtype=torch.float32, device=self.device) if need_cand else None]
+        N.check(self.lib.okge_prefix_score_backward(N.SCORERS[scorer] if isinstance(scorer, str) else int(scorer), 1 if sp else 0,
+                                                    g.data_ptr(), g.stride(0), b, n, ent.data_ptr(), ent.stride(0), rel.data_ptr(),
+                                                    rel.stride(0), cand.data_ptr(), cand.stride(0), d, _ptr(out[0]), _ptr(out[1]),
+                                                    _ptr(out[2]), self._sb_ws.data_ptr(), self._sb_ws.numel(), self._stream()),
+                "okge_prefix_score_backward")
+        return out
+
+    def scatter_rows(self, rows, ids, first_id, table_grad, drop: DropoutSpec = NO_DROP):
+        """table_grad[id] += masked rows of the positions naming id, summed in sorted-position order (okge_scatter_rows)"""
+        n, d = rows.shape
+        order = None
+        if ids is not None:
+            ids = _i32(ids, self.device)
+            order = torch.argsort(ids, stable=True).to(torch.int32)          # (index plumbing; the sums are the kernel's)
+        dc = drop.c()
+        N.check(self.lib.okge_scatter_rows(rows.data_ptr(), rows.stride(0), _ptr(ids), _ptr(order), int(first_id), n, d, ctypes.byref(dc),
+                                           table_grad.data_ptr(), table_grad.shape[0], self._stream()), "okge_scatter_rows")
+        return table_grad
+
     def scale_(self, x, alpha_dev):
         """x *= alpha (device fp32 scalar) in place."""
         N.check(self.lib.okge_scale_inplace(x.data_ptr(), x.numel(), alpha_dev.data_ptr(), self._stream()),

@@ -43,6 +43,9 @@ Vectors:
                   collate built with batch-shared sampled candidates (N = 10 000): loss, score slice, gradient checksums
   g13_valid_pass  reference-trained tables (rounded to bf16, stored 16-bit) + the reference's evaluation over ALL of
                   FB15k-237 valid.txt (its loader, collate, eval-mode AddLossModule, compute_metrics): per-group ranks, meters
+  g15_epochs      three whole training passes of the reference over its own loader (test.txt as the training split, shuffle off,
+                  dropout 0): per-step loss / normalizer, rows and positives per batch; then its evaluation over all of
+                  valid.txt on the trained fp32 tables: meters
   g11_traj_*      30 training steps at the BASELINE size on real FB15k-237 batches (reference dataset + collate), then
                   filtered ranks / MRR of the first valid.txt batch on the trained tables
 """
@@ -895,6 +898,86 @@ def g13():
 
 
 # ----------------------------------------------------------------------------------------------
+# G15: epoch-scale training parity -- whole passes of Trainer.train's arithmetic over the reference's own loader
+# ----------------------------------------------------------------------------------------------
+def g15():
+    """The reference trains LookupComplexRelationModel d=200 (AddLossModule bce, OptimRegime Adagrad lr 0.3 wd 1e-10,
+    input_dropout 0 so that the run is a function of the data alone) for THREE passes over its own loader on test.txt (the
+    stand-in training split), shuffle off, drop_last on -- the loop of Trainer.compute_one_epoch (trainer.py:274-354,
+    :217-257) statement for statement.  Stored per step: loss / normalizer, rows (po, sp) and positives of the batch (so the
+    test can check it feeds the same batches); after the last pass the reference's evaluation over ALL of valid.txt on the
+    trained fp32 tables (as in g13): meters.  The initial tables are regenerated from the seed by the test (checksums)."""
+    import shutil
+    import tempfile
+    fb = "/root/reference/data/fb15k237/mapped_to_ids"
+    scratch = tempfile.mkdtemp(prefix="okge_g15_")
+    try:
+        for f in os.listdir(fb):
+            shutil.copy(os.path.join(fb, f), scratch)
+        files = {"train": "test.txt", "valid": "valid.txt", "test": "test.txt"}
+        ds = {}
+        for split in ("train", "valid"):
+            ds[split] = OneToNMentionRelationDataset(dataset_dir=scratch, input_file=files[split],
+                                                     is_training_data=(split == "train"), batch_size=512, copy_data_to_dev_shm=False)
+        for split in ("train", "valid"):
+            ds[split].merge_all_splits_triples(dataset_dir=scratch, train_input_file=files["train"],
+                                               valid_input_file=files["valid"], test_input_file=files["test"])
+            ds[split].create_data_tensors(dataset_dir=scratch, train_input_file=files["train"],
+                                          valid_input_file=files["valid"], test_input_file=files["test"])
+        tr, v = ds["train"], ds["valid"]
+        n_ent, n_rel = v.entity_vocab_size, v.relations_size
+        seed, d, lr, n_epochs = 2027, 200, 0.3, 3
+        m = make_model("LookupComplexRelationModel", n_ent, n_rel, d, seed=seed, input_dropout=0.0, init_std=0.1)
+        E0, R0 = m.entity_embedding.weight.detach().numpy().copy(), m.relation_embedding.weight.detach().numpy().copy()
+        table_check = np.asarray([E0.sum(dtype=np.float64), np.abs(E0).sum(dtype=np.float64), R0.sum(dtype=np.float64),
+                                  float(E0[5, 7]), float(E0[-1, -1]), float(R0[3, 4])])
+        m.train()
+        args = {"optimization_config": {"optimizer": "Adagrad", "epoch": 0, "lr": lr, "weight_decay": 1.0e-10},
+                "lr_scheduler_config": None}
+        opts = OptimRegime.setup_optimizer_regime(args=args, model=m)
+        mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+        mod.train()
+        step, losses, shape = 0, [], []
+        for epoch in range(n_epochs):
+            for batch in tr.get_loader(shuffle=False, num_workers=0, drop_last=True):
+                inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = batch
+                step += 1
+                for o in opts:
+                    o.update(epoch + 1, step)
+                    o.zero_grad()
+                loss, _, _ = mod(inputs=list(inputs), labels=labels, use_batch_shared_entities=False,
+                                 batch_shared_entities=cand, epoch=epoch + 1, input_style_triple_or_prefix="right_and_left_prefix")
+                (loss.sum() / float(norm_loss)).backward()
+                for o in opts:
+                    o.step()
+                losses.append(loss.item() / float(norm_loss))
+                n_po = 0 if inputs[0] is None else int(inputs[0][0].shape[0])
+                n_sp = 0 if inputs[1] is None else int(inputs[1][0].shape[0])
+                shape.append((n_po, n_sp, int(labels.sum().item()), float(norm_loss)))
+        print("g15: trained", step, "steps in", n_epochs, "passes; loss/normalizer", losses[0], "->", losses[-1])
+        mod.eval()
+        total = None
+        with torch.no_grad():
+            for batch in v.get_loader(shuffle=False, num_workers=0, drop_last=False):
+                inputs, norm_loss, norm_metric, labels, label_ids, filt, cand = batch
+                loss, _, outputs = mod(inputs=list(inputs), labels=labels, use_batch_shared_entities=False,
+                                       batch_shared_entities=cand, epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+                res = OneToNMentionRelationDataset.compute_metrics(filter_mask=filt, label_ids=label_ids, predictions=outputs.clone())
+                total = res if total is None else total + res
+        print("g15: valid mrr", total["mrr"].avg, "h10", total["h10"].avg)
+        E1, R1 = m.entity_embedding.weight.detach().numpy(), m.relation_embedding.weight.detach().numpy()
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    save("g15_epochs_fb15k237", seed=np.int64(seed), n_ent=np.int64(n_ent), n_rel=np.int64(n_rel), d=np.int64(d), lr=np.float64(lr),
+         n_epochs=np.int64(n_epochs), batch_size=np.int64(512), table_check=table_check, losses=np.asarray(losses, np.float64),
+         batch_shape=np.asarray(shape, np.float64), final_check=np.asarray([E1.sum(dtype=np.float64), np.abs(E1).sum(dtype=np.float64),
+                                                                           R1.sum(dtype=np.float64), np.abs(R1).sum(dtype=np.float64)]),
+         E_rows=E1[[2, 100, 5000, 14000]].copy(), R_rows=R1[[2, 50, 200]].copy(),
+         **{"m_" + k: np.float64(val.avg) for k, val in total.items() if k != "loss"},
+         **{"c_" + k: np.float64(val.count) for k, val in total.items() if k != "loss"})
+
+
+# ----------------------------------------------------------------------------------------------
 # G14: BASELINE configs[2] at its size through the reference: LookupDistmultRelationModel d = 512, batch-shared sampled candidates
 # ----------------------------------------------------------------------------------------------
 def g14():
@@ -1061,7 +1144,7 @@ def g8():
 
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
         if fn is g12 and any(a.startswith("g12:") for a in only):    # `make_golden.py g12:all_noshare`: one case of the family
             fn(tuple(a[4:] for a in only if a.startswith("g12:")))
         elif not only or fn.__name__ in only:
