@@ -366,6 +366,25 @@ typedef struct okge_adagrad_tensor {
 int okge_adagrad_multi(const okge_adagrad_tensor *tensors, int32_t n_tensors, float lr, float weight_decay, float eps,
                        void *stream);
 
+/* ---- the whole step in one call: okge_train_forward_backward + the dense Adagrad update of both tables ------------------
+ * (Trainer.compute_one_batch's training branch end to end, trainer.py:217-257 with utils/optim.py:139-160.)  Same arithmetic,
+ * element for element, as okge_train_forward_backward followed by okge_adagrad_step2(zero_grad = 2 or 1) -- tables and
+ * accumulators end up bit-identical -- but the update rides in the step's own launches: the sweep over the entity rows that no
+ * prefix of the batch names (their gradient is final once the tile kernel has run) runs in extra workgroups of the
+ * prefix-backward launch, which is latency-bound and leaves the memory system idle; one small launch finishes the <= B prefix
+ * entity rows and the relation table (gradient cleared).  prefix_flags: n_ent int32 words the caller zeroes ONCE and thereafter
+ * only hands to this function (it leaves them zero).  zero_entity_grad: clear dE as okge_adagrad_step does; 0 when the next step
+ * overwrites every candidate row anyway (1-vs-all with OKGE_TRAIN_GRADS_ZERO). */
+typedef struct okge_adagrad {
+    float *sum_E, *sum_R;
+    float lr, weight_decay, eps;
+    int32_t zero_entity_grad;
+    int32_t *prefix_flags;
+} okge_adagrad;
+int okge_train_step(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand, const okge_positives *pos,
+                    int32_t loss_kind, float label_smoothing, double normalizer, int32_t flags, const okge_adagrad *opt,
+                    double *loss_out, float *dE, float *dR, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- batch producer (HOST pointers; no device work) ---------------------------------------------------
  * Replaces OneToNMentionRelationDataset_collate_func (dataset.py:724-940) and the packed answer-group decoding
  * it uses (utils/misc.py:72-89).  The dataset is the reference's three int32 tensors (dataset.py:567-710):

@@ -493,7 +493,8 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
                       int64_t ldq_ext, int32_t B, const okge_candidates *cand, const okge_positives *pos,
                       int32_t loss_kind, float label_smoothing, double normalizer, int32_t n_cand_global, int32_t flags,
                       double *loss_out, float *dE, float *dR, float *dq_out, float *scores, int64_t ld_scores,
-                      const float *row_lse_ext, void *workspace, size_t workspace_bytes, void *stream)
+                      const float *row_lse_ext, void *workspace, size_t workspace_bytes, void *stream,
+                      const okge_adagrad *opt = nullptr)
 {
     if (!pos || pos->nnz < 0 || (pos->nnz > 0 && (!pos->col || !pos->row)))
         return fail(OKGE_ERR_INVALID, "bad positives");
@@ -531,10 +532,11 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
             clr.p[1] = dE;                      clr.n[1] = (int64_t)cand->first_id * d64;
             clr.p[2] = dE + hi * d64;           clr.n[2] = ((int64_t)t->n_ent - hi) * d64;
         }
+        if (opt) clr.prefix_flags = opt->prefix_flags;
         e = launch_encode_queries(t->E, t->R, t->d, t->scorer, p, reinterpret_cast<float *>(ws + g.off_Q), g.ldq,
                                   q_ext ? 0 : g.Bpad, nullptr, pos->col, pos->nnz,
                                   reinterpret_cast<int32_t *>(ws + g.off_tptr), g.ktiles, g.tile_w, cand_col0, st,
-                                  (clear_grads || kl_own_lse) ? &clr : nullptr);
+                                  (clear_grads || kl_own_lse || opt) ? &clr : nullptr);
         if (e != hipSuccess) return fail_hip(e, "encode_queries");
     }
     FusedArgs a;
@@ -671,10 +673,21 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
     {
         ScopedTimer tm("prefix_backward", st);      // + the deterministic loss reduction (one extra workgroup)
         const PrefixDev p = to_dev(*batch, t, sh);
+        AdagradFuse af = {};
+        if (opt) {
+            af.E = const_cast<float *>(t->E); af.sumE = opt->sum_E; af.dE = dE; af.R = const_cast<float *>(t->R); af.sumR = opt->sum_R; af.dR = dR;
+            af.flags = opt->prefix_flags; af.n_ent = t->n_ent; af.n_rel = t->n_rel; af.d = t->d; af.zero_dE = opt->zero_entity_grad; af.on = 1;
+            af.lr = opt->lr; af.wd = opt->weight_decay; af.eps = opt->eps;
+        }
         e = launch_prefix_backward(t->E, t->R, t->d, t->scorer, p, q.slab, g.nsplit, g.Bpad, g.ldq, nullptr, dE, dR,
                                    a.loss_partial, n_loss_partials, loss_out, st, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr,
-                                   (flags & OKGE_TRAIN_DISTINCT_PREFIX_ROWS) ? 1 : 0);
+                                   (flags & OKGE_TRAIN_DISTINCT_PREFIX_ROWS) ? 1 : 0, opt ? &af : nullptr);
         if (e != hipSuccess) return fail_hip(e, "prefix_backward");
+        if (opt) {
+            ScopedTimer tf("adagrad_finish", st);
+            e = launch_adagrad_finish(af, p, st);
+            if (e != hipSuccess) return fail_hip(e, "adagrad_finish");
+        }
     }
     return OKGE_OK;
 }
@@ -690,6 +703,23 @@ int okge_train_forward_backward(const okge_tables *t, const okge_prefix_batch *b
     return train_core(t, nullptr, batch, nullptr, 0, batch->n_po + batch->n_sp, cand, pos, loss_kind, label_smoothing,
                       normalizer, cand->n, flags, loss_out, dE, dR, nullptr, scores, ld_scores, nullptr, workspace,
                       workspace_bytes, stream);
+}
+
+int okge_train_step(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand, const okge_positives *pos,
+                    int32_t loss_kind, float label_smoothing, double normalizer, int32_t flags, const okge_adagrad *opt,
+                    double *loss_out, float *dE, float *dR, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_common(t, batch, cand)) return rc;
+    if (!dR || !opt || !opt->sum_E || !opt->sum_R || !opt->prefix_flags) return fail(OKGE_ERR_INVALID, "null output / optimizer state");
+    if (flags & (OKGE_TRAIN_LOSS_ONLY | OKGE_TRAIN_DISTINCT_PREFIX_ROWS))
+        return fail(OKGE_ERR_INVALID, "okge_train_step updates the tables: not with LOSS_ONLY / DISTINCT_PREFIX_ROWS");
+    if (t->scorer == OKGE_DISTMULT ? t->d % 4 : t->d % 8)
+        return fail(OKGE_ERR_UNSUPPORTED, "okge_train_step needs a slot size that is a multiple of 4 (DistMult) / 8 (ComplEx)");
+    if ((reinterpret_cast<uintptr_t>(t->E) | reinterpret_cast<uintptr_t>(t->R) | reinterpret_cast<uintptr_t>(dE) | reinterpret_cast<uintptr_t>(dR) |
+         reinterpret_cast<uintptr_t>(opt->sum_E) | reinterpret_cast<uintptr_t>(opt->sum_R)) % 16)
+        return fail(OKGE_ERR_INVALID, "tables, gradients and accumulators must be 16-byte aligned");
+    return train_core(t, nullptr, batch, nullptr, 0, batch->n_po + batch->n_sp, cand, pos, loss_kind, label_smoothing, normalizer,
+                      cand->n, flags, loss_out, dE, dR, nullptr, nullptr, 0, nullptr, workspace, workspace_bytes, stream, opt);
 }
 
 // ---- entity-sharded phases ---------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y,
 // up to four float regions cleared by extra workgroups of encode_queries_kernel (OKGE_TRAIN_CLEAR_GRADS: dR, dE in front of
 // and behind the candidates; the KL loss' per-row label mass before it is counted)
 constexpr int CLEAR_REGIONS = 4;
-struct ClearSpec { float *p[CLEAR_REGIONS]; int64_t n[CLEAR_REGIONS]; };
+struct ClearSpec { float *p[CLEAR_REGIONS]; int64_t n[CLEAR_REGIONS]; int32_t *prefix_flags; };   // prefix_flags: [n_ent] words, set to 1 for every prefix entity row (okge_train_step)
 hipError_t launch_encode_queries(const float *E, const float *R, int d, int scorer, const PrefixDev &p, float *Q,
                                  int ldq, int Bpad, float *ent_rows, const int32_t *pos_col, int nnz, int32_t *tile_ptr,
                                  int tiles, int tile_w, int cand_col0, hipStream_t st, const ClearSpec *clear = nullptr);
@@ -108,12 +108,24 @@ hipError_t launch_fold_queries(const float *R, int d, int scorer, const PrefixDe
                                int Bpad, hipStream_t st);
 hipError_t launch_slab_reduce(const float *slab, int nsplit, int64_t n, float *out, const double *loss_partials,
                               int n_partials, double *loss_out, hipStream_t st);
+// okge_train_step: the dense Adagrad update folded into the step's last launches.  The sweep over the entity rows NO prefix of
+// the batch names (their gradient is final once the tile kernel has run) rides in extra workgroups of the prefix-backward launch --
+// a latency-bound launch of B one-row workgroups that leaves the memory system idle --, and a small launch finishes the <= B
+// flagged rows (they receive prefix gradients in that launch) and the relation table.
+struct AdagradFuse {
+    float   *E, *sumE, *dE, *R, *sumR, *dR;
+    int32_t *flags;                    // [n_ent]: 1 = a prefix entity of this batch (set by the encode launch, cleared by the finish)
+    int64_t  n_ent;
+    int32_t  n_rel, d, zero_dE, on;
+    float    lr, wd, eps;
+};
 hipError_t launch_prefix_backward(const float *E, const float *R, int d, int scorer, const PrefixDev &p,
                                   const float *slab, int nsplit, int Bpad, int ldq, const float *ent_rows, float *dE,
                                   float *dR, const double *loss_partials, int n_partials, double *loss_out,
                                   hipStream_t st, const int32_t *rel_order = nullptr, const int32_t *rel_seg_ptr = nullptr,
                                   int n_rel_seg = 0, const int32_t *ent_order = nullptr, const int32_t *ent_seg_ptr = nullptr,
-                                  int n_ent_seg = 0, float *grad_rows = nullptr, int distinct = 0);
+                                  int n_ent_seg = 0, float *grad_rows = nullptr, int distinct = 0, const AdagradFuse *fuse = nullptr);
+hipError_t launch_adagrad_finish(const AdagradFuse &af, const PrefixDev &p, hipStream_t st);
 hipError_t launch_loss_reduce(const double *partials, int n, double *loss_out, hipStream_t st);
 hipError_t launch_kl_count_pos(const int32_t *pos_row, int nnz, int Bpad, float *row_ysum, hipStream_t st);
 hipError_t launch_kl_row_lse(const float *stats, int tiles, int B, int Bpad, float *run, int first, int last, float *row_lse,

@@ -108,6 +108,10 @@ __global__ __launch_bounds__(128) void encode_queries_kernel(const float *__rest
         return;
     }
     const int b = blockIdx.x;
+    if (clr.prefix_flags && threadIdx.x == 0 && b < p.n_po + p.n_sp) {              // okge_train_step: this row's entity gets prefix gradients
+        const RowSrc rs = row_source(p, b, false);
+        if (rs.owned) clr.prefix_flags[rs.ent] = 1;
+    }
     encode_query_row(E, R, d, scorer, p, b, Q ? Q + (size_t)b * ldq : nullptr,      // Q == nullptr: only the masked
                      ent_rows ? ent_rows + (size_t)b * ldq : nullptr, ldq);         // entity rows are wanted
 }
@@ -346,6 +350,83 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v)
 // NB: slab loads kept in flight per lane (8 for the single-device step's 32 split-K slabs; 1 for the sharded step, whose dQ
 // arrives already reduced: 89 instead of 149 registers = 5 instead of 3 waves per SIMD, which is what bounds a launch of
 // 4096 one-row workgroups -- 2.7 rounds of a ~7 us dependent-load chain at 3 waves)
+__device__ __forceinline__ bool bits_differ(const float4 &a, const float4 &b)
+{
+    return ((__float_as_uint(a.x) ^ __float_as_uint(b.x)) | (__float_as_uint(a.y) ^ __float_as_uint(b.y)) |
+            (__float_as_uint(a.z) ^ __float_as_uint(b.z)) | (__float_as_uint(a.w) ^ __float_as_uint(b.w))) != 0u;
+}
+
+// ---- okge_train_step: Adagrad inside the step's last launches (AdagradFuse, okge_kernels.h) -------------------------------
+__device__ __forceinline__ void adagrad4(float4 &pv, const float4 &gv, float4 &sv, float lr, float wd, float eps)
+{
+    float *pp = &pv.x, *ss = &sv.x;
+    const float *gg = &gv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // the arithmetic of adagrad_sweep, element for element
+        const float gj = fmaf(wd, pp[j], gg[j]);
+        ss[j] = fmaf(gj, gj, ss[j]);
+        pp[j] = pp[j] - lr * (gj / (sqrtf(ss[j]) + eps));
+    }
+}
+
+// entity rows without a prefix flag: their gradient row is final (the tile kernel stored it, no prefix of the batch names them)
+__device__ __forceinline__ void fused_entity_sweep(const AdagradFuse &af, int wg, int n_wgs)
+{
+    const uint32_t row4 = (uint32_t)af.d >> 2;
+    const int64_t n4 = af.n_ent * row4, stride = (int64_t)n_wgs * blockDim.x;
+    float4 *p4 = reinterpret_cast<float4 *>(af.E), *g4 = reinterpret_cast<float4 *>(af.dE), *s4 = reinterpret_cast<float4 *>(af.sumE);
+    for (int64_t i = (int64_t)wg * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        // (the flag is requested WITH the row data, not before it: one round trip; a flagged row's loads are wasted, there are <= B)
+        const int32_t flagged = af.flags[(uint32_t)i / row4];
+        float4 pv = p4[i], sv = s4[i];
+        const float4 gv = g4[i], p_old = pv, s_old = sv;
+        if (flagged != 0) continue;
+        adagrad4(pv, gv, sv, af.lr, af.wd, af.eps);
+        if (bits_differ(pv, p_old)) p4[i] = pv;
+        if (bits_differ(sv, s_old)) s4[i] = sv;
+        if (af.zero_dE && ((__float_as_uint(gv.x) | __float_as_uint(gv.y) | __float_as_uint(gv.z) | __float_as_uint(gv.w)) != 0u))
+            g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// the rest: workgroup b < B claims its batch row's prefix entity row (the flag goes back to 0: several batch rows may name one
+// entity, one of them updates it), the workgroups behind sweep the relation table (gradient cleared, as okge_adagrad_step2 does)
+__global__ __launch_bounds__(128) void adagrad_finish_kernel(const AdagradFuse af, const PrefixDev p, int B)
+{
+    __shared__ int64_t claimed;
+    const uint32_t row4 = (uint32_t)af.d >> 2;
+    if ((int)blockIdx.x < B) {
+        if (threadIdx.x == 0) {
+            const RowSrc rs = row_source(p, blockIdx.x, false);
+            claimed = (rs.owned && atomicExch(&af.flags[rs.ent], 0) != 0) ? rs.ent : -1;
+        }
+        __syncthreads();
+        const int64_t row = claimed;
+        if (row < 0) return;
+        float4 *p4 = reinterpret_cast<float4 *>(af.E) + row * row4, *g4 = reinterpret_cast<float4 *>(af.dE) + row * row4;
+        float4 *s4 = reinterpret_cast<float4 *>(af.sumE) + row * row4;
+        for (uint32_t i = threadIdx.x; i < row4; i += blockDim.x) {
+            float4 pv = p4[i], sv = s4[i];
+            const float4 gv = g4[i];
+            adagrad4(pv, gv, sv, af.lr, af.wd, af.eps);
+            p4[i] = pv;
+            s4[i] = sv;
+            if (af.zero_dE) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const int64_t n4 = (int64_t)af.n_rel * row4, stride = (int64_t)(gridDim.x - B) * blockDim.x;
+    float4 *p4 = reinterpret_cast<float4 *>(af.R), *g4 = reinterpret_cast<float4 *>(af.dR), *s4 = reinterpret_cast<float4 *>(af.sumR);
+    for (int64_t i = (int64_t)(blockIdx.x - B) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pv = p4[i], sv = s4[i];
+        const float4 gv = g4[i], p_old = pv, s_old = sv;
+        adagrad4(pv, gv, sv, af.lr, af.wd, af.eps);
+        if (bits_differ(pv, p_old)) p4[i] = pv;
+        if (bits_differ(sv, s_old)) s4[i] = sv;
+        if ((__float_as_uint(gv.x) | __float_as_uint(gv.y) | __float_as_uint(gv.z) | __float_as_uint(gv.w)) != 0u) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *__restrict__ E, const float *__restrict__ R,
                                                                   int d, int scorer, const PrefixDev p,
@@ -355,12 +436,16 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
                                                                   const double *__restrict__ loss_partials,
                                                                   int n_partials, double *__restrict__ loss_out,
                                                                   float *__restrict__ dr_rows, float *__restrict__ de_rows,
-                                                                  int distinct)
+                                                                  int distinct, const AdagradFuse af, int B_rows)
 {
+    if ((int)blockIdx.x > B_rows) {                      // okge_train_step: workgroups behind the loss reduction sweep the entity table
+        fused_entity_sweep(af, (int)blockIdx.x - B_rows - 1, (int)gridDim.x - B_rows - 1);
+        return;
+    }
     // dr_rows / de_rows ([B][ldq] each, or nullptr): the relation- / entity-gradient row of every batch row is STORED there
     // instead of being added into dR / dE with float atomics -- row_segment_sum_kernel then adds up the rows of each
     // relation / entity (okge_prefix_backward_segmented)
-    if (blockIdx.x == gridDim.x - 1) {
+    if ((int)blockIdx.x == B_rows) {
         if (loss_partials) loss_reduce_block(loss_partials, n_partials, loss_out);
         return;
     }
@@ -562,12 +647,6 @@ __global__ __launch_bounds__(256) void kl_row_lse_kernel(const float *__restrict
         if (last) row_lse[b] = M + logf(S);
         else run[b] = make_float2(M, S);
     }
-}
-
-__device__ __forceinline__ bool bits_differ(const float4 &a, const float4 &b)
-{
-    return ((__float_as_uint(a.x) ^ __float_as_uint(b.x)) | (__float_as_uint(a.y) ^ __float_as_uint(b.y)) |
-            (__float_as_uint(a.z) ^ __float_as_uint(b.z)) | (__float_as_uint(a.w) ^ __float_as_uint(b.w))) != 0u;
 }
 
 __global__ __launch_bounds__(256) void adagrad_kernel(float *__restrict__ p, float *__restrict__ g,
@@ -1146,22 +1225,29 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
                                   float *dR, const double *loss_partials, int n_partials, double *loss_out,
                                   hipStream_t st, const int32_t *rel_order, const int32_t *rel_seg_ptr, int n_rel_seg,
                                   const int32_t *ent_order, const int32_t *ent_seg_ptr, int n_ent_seg, float *grad_rows,
-                                  int distinct)
+                                  int distinct, const AdagradFuse *fuse)
 {
     const int B = p.n_po + p.n_sp;
     if (B <= 0) return hipSuccess;
     const bool vec = scorer == SC_DISTMULT ? (d % 4 == 0) : (d % 8 == 0);
+    if (fuse && !vec) return hipErrorInvalidValue;
     if (vec) {
         // grad_rows: [2][Bpad][ldq] scratch -- relation rows, then entity rows
         const bool seg_r = grad_rows && rel_order && rel_seg_ptr && n_rel_seg > 0;
         const bool seg_e = grad_rows && ent_order && ent_seg_ptr && n_ent_seg > 0;
         float *dr_rows = seg_r ? grad_rows : nullptr, *de_rows = seg_e ? grad_rows + (size_t)Bpad * ldq : nullptr;
+        AdagradFuse af = {};
+        int sweep_wgs = 0;
+        if (fuse) {
+            af = *fuse;
+            sweep_wgs = (int)std::min<int64_t>(16384, (af.n_ent * (d / 4) + 127) / 128);     // one float4 per thread up to 2 M of them
+        }
         if (nsplit >= 8)
-            hipLaunchKernelGGL(prefix_backward_vec_kernel<8>, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
-                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct);
+            hipLaunchKernelGGL(prefix_backward_vec_kernel<8>, dim3(B + 1 + sweep_wgs), dim3(128), 0, st, E, R, d, scorer, p, slab,
+                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct, af, B);
         else
-            hipLaunchKernelGGL(prefix_backward_vec_kernel<1>, dim3(B + 1), dim3(128), 0, st, E, R, d, scorer, p, slab,
-                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct);
+            hipLaunchKernelGGL(prefix_backward_vec_kernel<1>, dim3(B + 1 + sweep_wgs), dim3(128), 0, st, E, R, d, scorer, p, slab,
+                               nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct, af, B);
         if (seg_r || seg_e) {
             const RowSegments rel{rel_order, rel_seg_ptr, seg_r ? n_rel_seg : 0}, ent{ent_order, ent_seg_ptr, seg_e ? n_ent_seg : 0};
             hipLaunchKernelGGL(row_segment_sum_kernel, dim3(rel.n_seg + ent.n_seg), dim3(128), 0, st, dr_rows, de_rows, ldq, d, p,
@@ -1173,6 +1259,15 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
         if (loss_partials)
             hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, loss_partials, n_partials, loss_out);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_adagrad_finish(const AdagradFuse &af, const PrefixDev &p, hipStream_t st)
+{
+    const int B = p.n_po + p.n_sp;
+    const int r_wgs = (int)std::min<int64_t>(256, ((int64_t)af.n_rel * (af.d / 4) + 127) / 128);
+    if (B + r_wgs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adagrad_finish_kernel, dim3(B + r_wgs), dim3(128), 0, st, af, p, B);
     return hipGetLastError();
 }
 

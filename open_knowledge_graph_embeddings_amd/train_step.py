@@ -39,6 +39,14 @@ class FusedTrainStep:
         # (batch_size_for_backward = accumulate x batch_size), clipped to `grad_clip` (global 2-norm) if > 0
         self.grad_clip, self.accumulate = float(grad_clip or 0.0), max(1, int(accumulate))
         self._accumulated = 0
+        # OKGE_FUSED_UPDATE=1: okge_train_step (the update inside the step's launches; needs no clipping / accumulation between
+        # backward and update).  Built and measured in round 4 (profiles/round4_ablation.md): tables
+        # bit-identical, S-FB 0.1302-0.1310 vs 0.1308-0.1313 ms/step -- under the 3 % bar, so the two-call sequence stays the default
+        import os
+        d = E.shape[1]
+        self.fuse_update = (os.environ.get("OKGE_FUSED_UPDATE", "0") == "1" and self.grad_clip == 0 and self.accumulate == 1
+                            and d % (4 if scorer == "distmult" else 8) == 0)
+        self._fuse_now, self._fused_done, self._opt = False, False, None
 
     def state_tensors(self):
         """every tensor a step mutates (GraphedTrainStep snapshots them around its warm-up)"""
@@ -90,6 +98,22 @@ class FusedTrainStep:
         eng = self.engine
         ws = eng.workspace(n_po + n_sp, n, t.d)
         flags = (N.OKGE_TRAIN_GRADS_ZERO if self._grads_zero else 0) | (N.OKGE_TRAIN_UNIQUE_CANDIDATES if batch.cand_unique else 0)
+        if self._fuse_now:
+            # the whole step incl. the Adagrad update in ONE library call (okge_train_step): the entity sweep rides in the
+            # prefix-backward launch, a small launch finishes the prefix rows and the relation table
+            if self._opt is None:
+                self._prefix_flags = torch.zeros(self.E.shape[0], dtype=torch.int32, device=self.E.device)
+                o = self._opt = N.AdagradOpt()
+                o.sum_E, o.sum_R, o.prefix_flags = self.sumE.data_ptr(), self.sumR.data_ptr(), self._prefix_flags.data_ptr()
+            o = self._opt
+            o.lr, o.weight_decay, o.eps = float(self.lr), float(self.weight_decay), float(self.eps)
+            o.zero_entity_grad = 0 if self._last_full else 1
+            N.check(eng.lib.okge_train_step(
+                ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), ctypes.byref(pos), N.LOSSES[self.loss], float(self.label_smoothing),
+                float(normalizer if normalizer is not None else (n_po + n_sp) * n), flags, ctypes.byref(o), self.loss_out.data_ptr(),
+                self.dE.data_ptr(), self.dR.data_ptr(), ws.data_ptr(), eng._ws_bytes, eng._stream()), "okge_train_step")
+            self._fused_done = True
+            return self.loss_out
         N.check(eng.lib.okge_train_forward_backward(
             ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), ctypes.byref(pos), N.LOSSES[self.loss], float(self.label_smoothing),
             float(normalizer if normalizer is not None else (n_po + n_sp) * n), flags, self.loss_out.data_ptr(), self.dE.data_ptr(),
@@ -129,8 +153,14 @@ class FusedTrainStep:
     def step(self, batch: H.PrefixBatch, normalizer=None):
         """forward + loss + backward; every `accumulate`-th call also clips (grad_clip > 0) and takes the Adagrad step"""
         self.steps += 1
+        self._fuse_now, self._fused_done = self.fuse_update, False
         loss = self.forward_backward(batch, normalizer)
+        self._fuse_now = False
         self._grads_zero = False
+        if self._fused_done:                 # the update happened inside the call (dR cleared; dE cleared unless 1-vs-all)
+            self._dE_stale = bool(self._last_full)
+            self._grads_zero = True
+            return loss
         self._accumulated += 1
         if self._accumulated < self.accumulate:
             return loss                      # trainer.py:233-234, 246-248: no optimizer step yet, gradients keep adding up

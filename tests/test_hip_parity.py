@@ -592,3 +592,66 @@ def test_train_step_lazy_gradient_clear(hp):
         ko.adagrad_step(R, ref["dR"], sR, 0.3)
     np.testing.assert_allclose(st.sumE.cpu().numpy(), sE, rtol=2e-4, atol=1e-12)     # accumulators see every gradient
     assert np.isclose(st.E.cpu().numpy(), E, rtol=1e-3, atol=1e-4).mean() > 0.999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fb_1vsall_dropout", "sampled_list_distmult", "kl"])
+def test_train_step_with_fused_update_is_bit_identical(okge_lib, monkeypatch, case):
+    """okge_train_step (the Adagrad update inside the step's last launches) against okge_train_forward_backward followed by
+    okge_adagrad_step2: the SAME arithmetic element for element -- tables and accumulators bit-equal after several steps,
+    except where float atomics order the prefix gradients (rows that several batch rows name: compared to 1e-6)"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    from open_knowledge_graph_embeddings_amd.train_step import FusedTrainStep
+    rng = np.random.default_rng(77)
+    if case == "sampled_list_distmult":
+        n_ent, n_rel, d, B, N, scorer, loss, p = 3000, 40, 64, 256, 900, "distmult", "bce", 0.0
+    elif case == "kl":
+        n_ent, n_rel, d, B, N, scorer, loss, p = 2000, 30, 200, 192, 1998, "complex", "kl", 0.0
+    else:
+        n_ent, n_rel, d, B, N, scorer, loss, p = 14543, 239, 200, 512, 14541, "complex", "bce", 0.4
+    E0 = (rng.standard_normal((n_ent, d)) * 0.1).astype(np.float32)
+    R0 = (rng.standard_normal((n_rel, d)) * 0.1).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+
+    def batches():
+        r2 = np.random.default_rng(5)
+        out = []
+        for _ in range(4):
+            rows = np.repeat(np.arange(B), 2)
+            cols = r2.integers(0, N, rows.size)
+            key = np.unique(cols.astype(np.int64) * B + rows)
+            kw = dict(cand_first=2, n_cand=N) if N == n_ent - 2 else dict(cand_ids=t(r2.permutation(np.arange(2, n_ent))[:N].astype(np.int32)), cand_unique=True)
+            out.append(H.PrefixBatch(po_rel=t(r2.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=t(r2.integers(2, n_ent, B // 2).astype(np.int32)),
+                                     sp_subj=t(r2.integers(2, n_ent, B // 2).astype(np.int32)), sp_rel=t(r2.integers(2, n_rel, B // 2).astype(np.int32)),
+                                     pos_row=t((key % B).astype(np.int32)), pos_col=t((key // B).astype(np.int32)), **kw))
+        return out
+    runs = {}
+    bs = batches()
+    for fused in ("1", "0"):
+        monkeypatch.setenv("OKGE_FUSED_UPDATE", fused)
+        st = FusedTrainStep(t(E0), t(R0), scorer, loss=loss, lr=0.3, input_dropout=p, seed=3)
+        assert st.fuse_update == (fused == "1")
+        first = float(st.step(bs[0])[0])
+        torch.cuda.synchronize()
+        after_one = (st.E.clone(), st.sumE.clone(), st.R.clone(), st.sumR.clone())
+        losses = [first] + [float(st.step(b)[0]) for b in bs[1:] + bs]
+        torch.cuda.synchronize()
+        runs[fused] = (after_one, (st.E.clone(), st.R.clone(), st.sumE.clone(), st.sumR.clone()), st.dR.clone(), losses)
+        if fused == "1":
+            assert int(st._prefix_flags.abs().sum()) == 0            # the flags are back to zero after every step
+    a, b = runs["1"], runs["0"]
+    # ONE step from the same state: every entity row no prefix names is bit-equal (same arithmetic, another launch); the <= B
+    # prefix rows and the relation table take float atomics in either run (their order is not fixed): 1e-6
+    prefix_rows = torch.cat([bs[0].po_obj, bs[0].sp_subj]).long().unique()
+    mask = torch.ones(n_ent, dtype=torch.bool, device="cuda")
+    mask[prefix_rows] = False
+    for x, y in zip(a[0][:2], b[0][:2]):
+        assert torch.equal(x[mask], y[mask])
+        np.testing.assert_allclose(x[~mask].cpu().numpy(), y[~mask].cpu().numpy(), rtol=0, atol=1e-6)
+    for x, y in zip(a[0][2:], b[0][2:]):                             # (the relation table: ~2 batch rows add into every row)
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=5e-6)
+    # eight steps: the runs stay together (the atomics' order noise of the prefix rows feeds the next step's queries)
+    np.testing.assert_allclose(a[3], b[3], rtol=2e-6)
+    for x, y in zip(a[1], b[1]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=5e-5)
+    assert float(a[2].abs().max()) == 0 and float(b[2].abs().max()) == 0
