@@ -282,7 +282,11 @@ def main():
     run = lambda i: step.step(batches[i % N_BATCHES])                       # noqa: E731
     if sharded:
         run = lambda i: step.step(batches[i % N_BATCHES], plan=plans[i % N_BATCHES], rel_segments=segs[i % N_BATCHES])   # noqa: E731
-    if not sharded and os.environ.get("OKGE_BENCH_GRAPH", "0") == "1":
+    # (sharded: the captured step carries its RCCL collectives -- exchange 1 as the all-reduce, since a plan's shapes vary per
+    #  batch -- validated at world size 1 by tests/test_sharded.py::test_sharded_step_captured_in_a_hip_graph_rccl_one_rank; a
+    #  rank's sharded step takes ~0.16 ms of host time to launch against ~0.15 ms on the device, so on a multi-GPU node the
+    #  replay (0.05-0.06 ms of host time) is the lever if the ranks turn out host-bound.  Opt-in until it has run on N > 1.)
+    if os.environ.get("OKGE_BENCH_GRAPH", "0") == "1":
         from open_knowledge_graph_embeddings_amd.train_step import GraphedTrainStep
         g0 = GraphedTrainStep(step, batches[0], pos_capacity=batches[0].nnz)
         graphs = [g0] + [GraphedTrainStep(step, b, pos_capacity=b.nnz, counter=g0.counter) for b in batches[1:]]

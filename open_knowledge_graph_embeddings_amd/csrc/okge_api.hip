@@ -524,8 +524,11 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
         std::memset(&p, 0, sizeof(p));
         if (!q_ext) p = to_dev(*batch, t, sh);
         ClearSpec clr = {};
-        const bool kl_own_lse = loss_kind == OKGE_LOSS_KL && !row_lse_ext && !sh;
-        if (kl_own_lse) { clr.p[3] = reinterpret_cast<float *>(ws + g.off_ysum); clr.n[3] = g.Bpad; }   // counted in lse_pass
+        // the KL loss' label mass per row is cleared HERE, by workgroups of this launch -- counted in lse_pass (own row
+        // log-sum-exp) or by kl_count_pos (sharded: the log-sum-exp arrives from the exchange).  Not with hipMemsetAsync: inside a
+        // captured HIP graph the memset node was not re-executed / ordered on replay (ROCm 7.2), the mass doubled every replay
+        const bool kl_own_lse = loss_kind == OKGE_LOSS_KL;
+        if (kl_own_lse) { clr.p[3] = reinterpret_cast<float *>(ws + g.off_ysum); clr.n[3] = g.Bpad; }
         if (clear_grads) {                        // all of dR; the rows of dE in front of and behind the candidate range
             const int64_t d64 = t->d, hi = (int64_t)cand->first_id + cand->n;
             clr.p[0] = dR;                      clr.n[0] = (int64_t)t->n_rel * d64;

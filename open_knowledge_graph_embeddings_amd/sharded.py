@@ -143,13 +143,19 @@ class ShardedTrainStep:
         import os
         self.force_exchange = os.environ.get("OKGE_SHARDED_FORCE_EXCHANGE") == "1"
 
+    def state_tensors(self):
+        """every tensor a step mutates (train_step.GraphedTrainStep snapshots them around its warm-up)"""
+        return [self.E, self.R, self.dE, self.dR, self.sumE, self.sumR]
+
     def _set_dropout(self, batch):
-        pe, pr, s, t = self.input_dropout, self.relation_input_dropout, self.seed, self.steps
-        batch.drop_cand = H.DropoutSpec(pe, s, H.STREAM_CAND, t)
-        batch.drop_po_ent = H.DropoutSpec(pe, s, H.STREAM_PO_ENT, t)
-        batch.drop_sp_ent = H.DropoutSpec(pe, s, H.STREAM_SP_ENT, t)
-        batch.drop_po_rel = H.DropoutSpec(pr, s, H.STREAM_PO_REL, t)
-        batch.drop_sp_rel = H.DropoutSpec(pr, s, H.STREAM_SP_REL, t)
+        # step_dev (attached by GraphedTrainStep): the kernels read the step from a device counter the graph increments, so a
+        # replay of the captured step -- collectives included -- draws fresh masks
+        pe, pr, s, t, sd = self.input_dropout, self.relation_input_dropout, self.seed, self.steps, getattr(self, "step_dev", None)
+        batch.drop_cand = H.DropoutSpec(pe, s, H.STREAM_CAND, t, step_dev=sd)
+        batch.drop_po_ent = H.DropoutSpec(pe, s, H.STREAM_PO_ENT, t, step_dev=sd)
+        batch.drop_sp_ent = H.DropoutSpec(pe, s, H.STREAM_SP_ENT, t, step_dev=sd)
+        batch.drop_po_rel = H.DropoutSpec(pr, s, H.STREAM_PO_REL, t, step_dev=sd)
+        batch.drop_sp_rel = H.DropoutSpec(pr, s, H.STREAM_SP_REL, t, step_dev=sd)
 
     def _entity_rows(self, batch, plan):
         """masked prefix entity rows of ALL prefixes on every rank: all-gather of the owned rows (plan) or all-reduce"""

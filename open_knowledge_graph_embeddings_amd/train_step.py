@@ -217,7 +217,9 @@ class GraphedTrainStep:
         del saved
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a sharded step carries RCCL collectives, and the process group's watchdog thread polls the events of
+        # earlier collectives while this thread captures -- under the default (global) mode that query aborts the process
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.counter += 1
             self.loss = inner.step(self.static, normalizer)
 

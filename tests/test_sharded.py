@@ -979,3 +979,52 @@ def test_sharded_step_rccl_one_rank_rehearsal(okge_lib, loss, monkeypatch):
         np.testing.assert_allclose(a.R.cpu().numpy(), f.R.cpu().numpy(), rtol=1e-4, atol=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss", ["bce", "kl"])
+def test_sharded_step_captured_in_a_hip_graph_rccl_one_rank(okge_lib, loss, monkeypatch):
+    """the SHARDED step -- RCCL collectives included (exchange 1 as all-reduce, the KL all-gather, the dQ all-reduce) -- captured
+    once in a HIP graph (train_step.GraphedTrainStep) and replayed: same losses and tables as the same step launched from
+    Python, fresh dropout masks per replay (device-side step counter).  One-rank group with the exchange path forced: every
+    collective call of a multi-GPU run is in the graph.  Also prints replay against launch time."""
+    import time
+    import torch.distributed as dist
+    from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep
+    from open_knowledge_graph_embeddings_amd.train_step import GraphedTrainStep
+    monkeypatch.setenv("OKGE_SHARDED_FORCE_EXCHANGE", "1")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        E, R = tables()
+        mk = lambda: ShardedTrainStep(torch.from_numpy(E.copy()).cuda(), torch.from_numpy(R.copy()).cuda(), SCORER, N_ENT, lr=LR,   # noqa: E731
+                                      input_dropout=P_DROP, seed=SEED, loss=loss)
+        plain, inner = mk(), mk()
+        assert plain.force_exchange and inner.force_exchange
+        batches = [to_batch(problem(step), "cuda:0") for step in range(1, 5)]
+        graphed = GraphedTrainStep(inner, batches[0], pos_capacity=max(b.nnz for b in batches) + 5)
+        np.testing.assert_array_equal(inner.E.cpu().numpy(), E)            # the capture warm-up left no trace
+        for i in range(6):
+            b = batches[i % 4]
+            lp, lg = float(plain.step(b)[0]), float(graphed.step(b)[0])
+            assert abs(lp - lg) <= 2e-6 * abs(lp), (i, lp, lg)
+        for a, b2 in ((inner.E, plain.E), (inner.R, plain.R)):           # (float atomics in the prefix scatter: order noise)
+            a, b2 = a.cpu().numpy(), b2.cpu().numpy()
+            assert np.isclose(a, b2, rtol=1e-4, atol=1e-5).mean() > 0.9999 and np.abs(a - b2).max() < 1e-3
+        times = {}
+        for name, fn in (("launched", lambda b: plain.step(b)), ("replayed", lambda b: graphed.step(b))):
+            for b in batches:
+                fn(b)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(200):
+                fn(batches[i % 4])
+            torch.cuda.synchronize()
+            times[name] = 1e3 * (time.perf_counter() - t0) / 200
+        print(f"[hip sharded graph, {loss}] ms/step launched {times['launched']:.4f}, replayed {times['replayed']:.4f}")
+    finally:
+        dist.destroy_process_group()
