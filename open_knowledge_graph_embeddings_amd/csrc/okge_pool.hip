@@ -422,13 +422,14 @@ __global__ __launch_bounds__(256) void bn_partial2_kernel(const PoolBatch pb, co
     }
 }
 
-// finish in double, one workgroup per (call, 16 columns), 16 threads per column each folding a sixteenth of the row-block
-// partials (4 per column and 64 columns per workgroup made this a 20-workgroup launch of 64-step dependent chains: 34 us):
+// finish in double, one workgroup per (call, FIN_COLS columns), FIN_PARTS threads per column each folding its share of the
+// row-block partials (4 per column and 64 columns per workgroup made this a 20-workgroup launch of 64-step dependent chains:
+// 34 us; 16 x 16: 13 us; 64 threads per column on 4 columns: 7 us at configs[4]):
 // STEP 0 -> saved = {mean, rstd, unbiased variance (for the running statistics, applied in call order by bn_apply_kernel's
 //           last workgroup)} of all n rows from the per-block (mean, M2) pairs;
 // STEP 2 -> this call's (dbias, dweight) into saved[2..3] (added to the parameter gradients in call order by
 //           pool_backward_kernel's last workgroup)
-constexpr int FIN_COLS = 16, FIN_PARTS = 16;
+constexpr int FIN_COLS = 4, FIN_PARTS = 64;      // (16 x 16 until round 4: 80 workgroups of 16-step dependent chains, 13 us; now 320 of 4 steps)
 template <int STEP>
 __global__ __launch_bounds__(256) void bn_finish_kernel(const PoolBatch pb, const ScatterBatch sb, int fin_blocks)
 {

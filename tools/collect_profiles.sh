@@ -10,6 +10,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export OKGE_BENCH_OLP=0      # the S-OLP leg has its own line in the bench output; keep the per-kernel averages S-FB only
+export OKGE_BENCH_CONFIGS=0  # ... and so do the other configurations (tools/collect_profiles_configs.sh profiles them)
 CMD="python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/bench_trace.json" 2> "$OUT/trace.err" || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $CMD > /dev/null 2> "$OUT/pmc_fetch.err" || exit 1
