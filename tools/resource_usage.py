@@ -25,6 +25,6 @@ for src in sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")):
             cur[k] = v
 print(f"{'kernel':100s} {'VGPR':>5s} {'AGPR':>5s} {'spillV':>6s} {'spillS':>6s} {'scratch':>7s} {'occ':>4s} {'LDS':>7s}")
 for r in rows:
-    name = re.sub(r"\(.*", "", r["name"]).replace("okge::", "").replace("(anonymous namespace)::", "").replace("void ", "")
+    name = re.sub(r"\(.*", "", r["name"].replace("(anonymous namespace)::", "")).replace("okge::", "").replace("void ", "")
     print(f"{(r['file'][5:-4] + ': ' + name)[:100]:100s} {r.get('VGPRs', ''):>5s} {r.get('AGPRs', ''):>5s} {r.get('VGPRs Spill', ''):>6s} "
           f"{r.get('SGPRs Spill', ''):>6s} {r.get('ScratchSize [bytes/lane]', ''):>7s} {r.get('Occupancy [waves/SIMD]', ''):>4s} {r.get('LDS Size [bytes/block]', ''):>7s}")

@@ -13,7 +13,7 @@ root = sys.argv[1]
 
 
 def short(name):
-    return name.split("(")[0].replace("void okge::", "").replace("okge::", "")
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void okge::", "").replace("okge::", "")
 
 
 def pmc(sub):
