@@ -498,14 +498,14 @@ int okge_evaluate_batch(const okge_tables *t, const okge_prefix_batch *batch, co
                         const int64_t *grp_ptr, const int32_t *ids, int64_t n_groups, float *scores, int64_t ld_scores,
                         int64_t *ranks, double *acc, void *workspace, size_t workspace_bytes, void *stream,
                         void *rank_stream);
-/* One evaluation batch WITHOUT the (B, N) score block (slot sizes up to 256, eval mode: no dropout): replaces
+/* One evaluation batch WITHOUT the (B, N) score block (slot sizes up to 512, eval mode: no dropout): replaces
  * Trainer.evaluate's per-batch body (trainer.py:258-272) + compute_metrics (dataset.py:423-453) by three launches on
  * `stream`: (1) the folded queries and the POINT scores the rank rule needs -- every answer group's true score and the
  * score under every filter entry -- as scalar fma chains in the tile kernel's summation order (bit-equal to the scores
  * okge_score_prefixes writes); (2) one sweep of the candidate tiles that compares the score block in registers with the
  * rows' true scores and adds {#greater, #equal} to per-group counters; (3) ranks (filter entries counted as -1e8) and
  * the seven meters added to acc[7].  ranks[] is bit-equal to okge_score_prefixes + okge_filtered_ranks.
- * n_filter = filt_ptr[B], n_groups = row_ptr[B] (host copies).  Returns OKGE_ERR_UNSUPPORTED for d > 256, dropout or a
+ * n_filter = filt_ptr[B], n_groups = row_ptr[B] (host copies).  Returns OKGE_ERR_UNSUPPORTED for d > 512, dropout or a
  * candidate table: use okge_evaluate_batch there. */
 size_t okge_eval_workspace_bytes(int32_t B, int32_t N, int32_t d, int64_t n_groups, int64_t n_filter);
 int okge_evaluate_fused(const okge_tables *t, const okge_prefix_batch *batch, const okge_candidates *cand,

@@ -1341,7 +1341,7 @@ static int eval_call(EvalCall &c, const okge_tables *t, const okge_prefix_batch 
     if (!filt_ptr || !row_ptr || !grp_ptr || (n_groups > 0 && !ids) || (!es && (!ranks || !acc)) || n_groups < 0 || n_filter < 0 ||
         (n_filter > 0 && !filt_col))                      // (a batch without answer groups has no ids array)
         return fail(OKGE_ERR_INVALID, "bad evaluate arguments");
-    if (t->d > 256) return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation covers slot sizes up to 256: use okge_evaluate_batch");
+    if (t->d > 512) return fail(OKGE_ERR_UNSUPPORTED, "slot sizes above 512 are not supported by the tile kernels");
     if (cand->table || cand->drop.p > 0.f || (batch && (batch->drop_po_ent.p > 0.f || batch->drop_sp_ent.p > 0.f ||
         batch->drop_po_rel.p > 0.f || batch->drop_sp_rel.p > 0.f)))
         return fail(OKGE_ERR_UNSUPPORTED, "fused evaluation is the eval-mode path (no dropout, candidates from the entity table)");
@@ -1403,7 +1403,9 @@ static int eval_issue(int phases, const EvalCall &c, hipStream_t st)
     }
     if (phases & 2) {
         ScopedTimer tm("fused_tile_count", st);
-        e = c.g.KB <= 16 ? launch_score_sweep(c.g, c.sweep, c.g.tiles, st, MODE_COUNT) : launch_fused(MODE_COUNT, c.sweep, c.g.tiles, 1, st);
+        // (slot sizes above 256: the register-tile kernel's counting mode in a stream-K launch; not on the OKGE_TILE_W=32 cut)
+        if (c.g.KB > 16 && c.g.tile_w == 32) return fail(OKGE_ERR_UNSUPPORTED, "the 32-wide cut (OKGE_TILE_W=32) has no counting sweep above slot size 256");
+        e = launch_score_sweep(c.g, c.sweep, c.g.tiles, st, MODE_COUNT);
         if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<count>");
     }
     if (phases & 4) {

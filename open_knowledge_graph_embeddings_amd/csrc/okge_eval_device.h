@@ -54,9 +54,12 @@ __device__ __forceinline__ RowSrc row_source(const PrefixDev &p, int b) { return
 __device__ __forceinline__ float point_score(const float *__restrict__ q /* LDS, zero padded to 16*KB */,
                                              const float *__restrict__ row, int d, int KB, bool vec_ok)
 {
-    float acc = 0.f;
+    // slot sizes above 256 (KB = 32, fused_tile64k_kernel): the tile's contraction is split over two waves -- columns 0 .. 255 and
+    // 256 .. 511, each a k-ordered chain of its own -- and the two partial scores are added once (a + b == b + a bit for bit)
+    float acc = 0.f, acc_lo = 0.f;
     constexpr int RB = 8;
     for (int r0 = 0; r0 < KB; r0 += RB) {
+        if (KB == 32 && r0 == 16) { acc_lo = acc; acc = 0.f; }
         float4 cv[RB][4];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
@@ -85,7 +88,7 @@ __device__ __forceinline__ float point_score(const float *__restrict__ q /* LDS,
                 for (int sl = 0; sl < 4; ++sl) acc = __fmaf_rn(q[16 * r + 4 * sl + j], c16[4 * sl + j], acc);
         }
     }
-    return acc;
+    return KB == 32 ? __fadd_rn(acc_lo, acc) : acc;
 }
 
 // One workgroup per batch row: the folded query row (-> Q for the tile sweep, and LDS), then the POINT scores the rank
@@ -102,7 +105,7 @@ __device__ __forceinline__ float point_score(const float *__restrict__ q /* LDS,
 // The kernel is a chain of dependent loads (ids -> rows, row_ptr -> grp_ptr -> ids -> rows), so it is written in stages
 // that issue everything whose address is known before waiting: (A) the row's CSR bounds and prefix ids, (B) the fold
 // operands, the group bounds / filter column of the thread's first item and the row-order counts, (C) the first answer
-// id, (D) the candidate rows.  Eval mode (no dropout: the entry point refuses it) and d <= 256: one column per thread.
+// id, (D) the candidate rows.  Eval mode (no dropout: the entry point refuses it); 256 threads fold up to 512 columns.
 __device__ __forceinline__ void eval_points_block(const EvalPointsArgs &a, int b)
 {
     __shared__ float qs[512];
@@ -123,12 +126,18 @@ __device__ __forceinline__ void eval_points_block(const EvalPointsArgs &a, int b
     // ---- stage B
     const int h = d >> 1;
     const bool cplx = a.scorer != SC_DISTMULT;
-    const bool act = rs.owned && tid < (cplx ? h : d);
-    float ea = 0.f, eb = 0.f, ra = 0.f, rb = 0.f;
-    if (act) {
+    const int n_fold = cplx ? h : d;                        // folded columns: one per thread, two above 256 (DistMult d <= 512)
+    float ea[2] = {0.f, 0.f}, eb[2] = {0.f, 0.f}, ra[2] = {0.f, 0.f}, rb[2] = {0.f, 0.f};
+    if (rs.owned) {
         const float *e = a.E + rs.ent * d, *r = a.R + rs.rel * d;
-        ea = e[tid]; ra = r[tid];
-        if (cplx) { eb = e[h + tid]; rb = r[h + tid]; }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = tid + it * nthr;
+            if (k < n_fold) {
+                ea[it] = e[k]; ra[it] = r[k];
+                if (cplx) { eb[it] = e[h + k]; rb[it] = r[h + k]; }
+            }
+        }
     }
     const int64_t g0 = g_lo + tid, f0 = f_lo + (nthr - 1 - tid);   // filter entries take the threads from the top: a row's
     const bool has_g = g0 < g_hi, has_f = f0 < f_hi;                // groups and filter entries run side by side
@@ -156,9 +165,15 @@ __device__ __forceinline__ void eval_points_block(const EvalPointsArgs &a, int b
     // the folded query row (model.py:205-216, :269-272; same roundings as encode_query_row with all masks = 1)
     for (int k = tid; k < 512; k += nthr) qs[k] = 0.f;
     __syncthreads();
-    if (act) {
-        if (cplx) fold_complex(rs.sp, ea, eb, ra, rb, qs[tid], qs[h + tid]);
-        else qs[tid] = __fmul_rn(ea, ra);
+    if (rs.owned) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = tid + it * nthr;
+            if (k < n_fold) {
+                if (cplx) fold_complex(rs.sp, ea[it], eb[it], ra[it], rb[it], qs[k], qs[h + k]);
+                else qs[k] = __fmul_rn(ea[it], ra[it]);
+            }
+        }
     }
     if (a.Q_in && in)                    // sharded: the row was folded from the exchanged entity rows (okge_fold_queries)
         for (int k = tid; k < 16 * KB; k += nthr) qs[k] = a.Q_in[(size_t)b * ldq + k];

@@ -62,10 +62,15 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
     constexpr int D16 = 16 * KB, KH = 16 * KBW;                 // padded slot size, columns of one half
     constexpr int NQ = 4 * KB, QG = 16, NQIT = NQ / QG;         // float4 per row; staging: 16 column groups per row
     static_assert(KB % 8 == 0, "the column split needs whole quads of 16-column blocks per wave");
-    static_assert(MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL || MODE == MODE_SCORE || MODE == MODE_STATS,
-                  "training kernel, or the score / statistics sweep");
+    static_assert(MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL || MODE == MODE_SCORE || MODE == MODE_STATS || MODE == MODE_COUNT,
+                  "training kernel, or the score / statistics / counting sweep");
     // MODE_SCORE / MODE_STATS: the same sweep stops after the score blocks and writes X, or per (16-candidate block, row) the
-    // (max, sum-exp) pairs of the KL loss' log-softmax (kl_row_lse_kernel merges them)
+    // (max, sum-exp) pairs of the KL loss' log-softmax (kl_row_lse_kernel merges them).
+    // MODE_COUNT (fused evaluation, round 4): the score product runs with its operands SWAPPED -- the result block is X^T, lane
+    // (c, s) holds row c's scores of candidates 4 s .. 4 s + 3 -- so that a row's comparison with its answer groups' true scores
+    // is lane-local; the chunk's packed {#greater | #equal << 16} counters are summed in LDS (the training modes' keep-flag /
+    // positives cache is free here) and leave as one coalesced store per (tile, chunk), as in fused_tile_kernel<count>.
+    // Same products in the same k order as MODE_SCORE: the counts equal those of the materialised scores bit for bit.
     constexpr bool TRAIN = MODE == MODE_TRAIN_BCE || MODE == MODE_TRAIN_KL;
     const int d = a.d;
     float *Qb = reinterpret_cast<float *>(smem);                              // [2][32][LDK]  (end: [64][LDK] gradient stage)
@@ -74,6 +79,8 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
     double *red = reinterpret_cast<double *>(ybits3 + 3 * 2 * BCK);           // [8]
     uint8_t *keepb = reinterpret_cast<uint8_t *>(red + 8);                    // [64][KEEP_LD] keep flags of the tile
     uint32_t *posc = reinterpret_cast<uint32_t *>(keepb + NTK * KEEP_LD);     // [POS_CACHE] (row << 6 | col)
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(keepb);                      // MODE_COUNT: [CNT_CAP] packed counters of a chunk's groups
+    constexpr int CNT_CAP = (NTK * KEEP_LD) / 4 + POS_CACHE;
 
     const bool vec_ok = (d & 3) == 0;
     const uint32_t dstep = a.drop_c.enabled ? drop_step(a.drop_c) : 0u;   // before the loads whose latency hides the masks
@@ -136,6 +143,24 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
         for (int it = 0; it < NQIT; ++it) *reinterpret_cast<v4f *>(dst + r16 * LDK + 4 * (q16 + QG * it)) = qreg[it];
     };
     fetch_chunk(b_begin);
+    // MODE_COUNT: the group range of the lane's row (row 16 ks + c of the chunk) one chunk ahead, its first RK_PRE true scores
+    // before the score product: the counting loop does not wait on dependent global loads
+    constexpr int RK_PRE = 4;
+    int64_t rk_glo = 0, rk_glo_n = 0, rk_c0 = 0, rk_c1 = 0, rk_c0_n = 0, rk_c1_n = 0;
+    int rk_ng = 0, rk_ng_n = 0;
+    float rk_t[RK_PRE];
+    auto rk_fetch_rows = [&](int b0) {
+        if (MODE != MODE_COUNT) return;
+        const int b = b0 + 16 * ks + c;
+        rk_glo_n = 0; rk_ng_n = 0;
+        if (b < b_end) {
+            rk_glo_n = a.rk_row_ptr[b];
+            rk_ng_n = (int)(a.rk_row_ptr[b + 1] - rk_glo_n);
+        }
+        rk_c0_n = a.rk_row_ptr[min(b0, b_end)];
+        rk_c1_n = a.rk_row_ptr[min(b0 + BCK, b_end)];
+    };
+    rk_fetch_rows(b_begin);
 
     const int pos_lo = TRAIN ? a.tile_ptr[tile] : 0, pos_hi = TRAIN ? a.tile_ptr[tile + 1] : 0;
     const int pos_cached = min(pos_hi - pos_lo, POS_CACHE);
@@ -232,6 +257,16 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
         const float *Qc = Qb + buf * (BCK * LDK);
         float *Qn = Qb + (buf ^ 1) * (BCK * LDK);
         if (b0 > b_begin) __syncthreads();   // chunk parked by everyone (during the previous chunk); the other buffer is free
+        if (MODE == MODE_COUNT) {
+            rk_glo = rk_glo_n; rk_ng = rk_ng_n;
+#pragma unroll
+            for (int jj = 0; jj < RK_PRE; ++jj)
+                rk_t[jj] = jj < rk_ng ? a.rk_true[rk_glo + jj] : __builtin_nanf("");      // NaN never compares true
+            rk_c0 = rk_c0_n; rk_c1 = rk_c1_n;
+            if (b0 + BCK < b_end) rk_fetch_rows(b0 + BCK);
+            if (a.rk_slab && rk_c1 - rk_c0 <= CNT_CAP)     // (read again after the chunk's mid barrier)
+                for (int k = tid; k < (int)(rk_c1 - rk_c0); k += TK_THREADS) cnt[k] = 0u;
+        }
         if (TRAIN) {   // under the score product: the next chunk's label bits, the buffer after that cleared
             const int pn = par == 2 ? 0 : par + 1, pc = pn == 2 ? 0 : pn + 1;
             if (tid < 2 * BCK) ybits3[pc * (2 * BCK) + tid] = 0u;
@@ -255,8 +290,13 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    x0 = mfma16(a00[j], breg[r][j], x0);
-                    x1 = mfma16(a01[j], breg[r][j], x1);
+                    if (MODE == MODE_COUNT) {           // X^T blocks: lane (c, s) = row c (+ 16), candidates 4 s + i
+                        x0 = mfma16(breg[r][j], a00[j], x0);
+                        x1 = mfma16(breg[r][j], a01[j], x1);
+                    } else {
+                        x0 = mfma16(a00[j], breg[r][j], x0);
+                        x1 = mfma16(a01[j], breg[r][j], x1);
+                    }
                 }
                 a00 = a10; a01 = a11;
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // ds_reads of round r+1
@@ -269,6 +309,61 @@ __global__ __launch_bounds__(TK_THREADS, 2) void fused_tile64k_kernel(const Fuse
         __syncthreads();
         x0 += xs[((w ^ 4) * 2 + 0) * 64 + lane];             // a + b == b + a: both partners hold the same bits
         x1 += xs[((w ^ 4) * 2 + 1) * 64 + lane];
+        if (MODE == MODE_COUNT) {
+            // partner ks takes row group ks: row b0 + 16 ks + c against candidates n0 + 16 blk + 4 s + i; the row's 64
+            // candidates of this tile sit in 16 lanes (s = 0 .. 3 of the four waves blk = 0 .. 3 of this ks)
+            const v4f xv = ks == 0 ? x0 : x1;
+            float xm[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xm[i] = n0 + 16 * blk + 4 * s + i < a.N ? xv[i] : -INFINITY;
+            const int64_t gc_lo = rk_c0, gc_hi = rk_c1, g_lo = rk_glo;
+            const int ng = rk_ng;
+            const bool in_lds = a.rk_slab && gc_hi - gc_lo <= CNT_CAP;
+            uint32_t *slab_row = a.rk_slab ? a.rk_slab + (size_t)tile * a.rk_ngroups : nullptr;
+            auto count_pass = [&](bool add) {
+                for (int j = 0; __builtin_amdgcn_ballot_w64(j < ng) != 0; ++j) {
+                    float t = j < ng && j >= RK_PRE ? a.rk_true[g_lo + j] : __builtin_nanf("");
+#pragma unroll
+                    for (int jj = 0; jj < RK_PRE; ++jj) t = j == jj ? rk_t[jj] : t;
+                    int pk = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pk += (xm[i] > t ? 1 : 0) + (xm[i] == t ? 65536 : 0);
+                    if (j < ng) {
+                        if (in_lds) {
+                            if (pk) atomicAdd(&cnt[g_lo + j - gc_lo], (uint32_t)pk);
+                        } else {
+                            pk += __shfl_xor(pk, 16);
+                            pk += __shfl_xor(pk, 32);
+                            if (s == 0) {
+                                if (slab_row) slab_row[g_lo + j] = add ? slab_row[g_lo + j] + (uint32_t)pk : (uint32_t)pk;
+                                else {
+                                    if (pk & 0xFFFF) atomicAdd(a.rk_counts + 2 * (g_lo + j), pk & 0xFFFF);
+                                    if (pk >> 16) atomicAdd(a.rk_counts + 2 * (g_lo + j) + 1, pk >> 16);
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            if (in_lds) {
+                count_pass(false);
+                __syncthreads();
+                for (int k = tid; k < (int)(gc_hi - gc_lo); k += TK_THREADS) slab_row[gc_lo + k] = cnt[k];
+            } else {
+                // more groups in the chunk than the LDS counters hold (or the atomics path of very large batches): the four
+                // waves that share a row take turns -- the first stores, the others add
+#pragma unroll 1
+                for (int turn = 0; turn < 4; ++turn) {
+                    if (blk == turn) count_pass(turn > 0);
+                    __syncthreads();
+                }
+            }
+            if (b0 + BCK < b_end) {
+                park_chunk(Qn);
+                if (b0 + 2 * BCK < b_end) fetch_chunk(b0 + 2 * BCK);
+            }
+            continue;
+        }
         if (MODE == MODE_SCORE) {
             // scores out: partner ks takes row group ks (rows 16 ks + 4 s + i, candidate 16 blk + c: 64-byte runs per row)
             const v4f x = ks == 0 ? x0 : x1;
@@ -490,9 +585,10 @@ hipError_t launch_fused64k(int mode, const FusedArgs &a, int grid_x, int grid_y,
     const dim3 grid(grid_x, grid_y);
     if (a.KB == 16 && (mode == MODE_TRAIN_BCE || mode == MODE_TRAIN_KL))      // experiment (OKGE_TILE64K_D256=1): d <= 256 on this layout
         return mode == MODE_TRAIN_KL ? launch64k_t<16, MODE_TRAIN_KL>(a, grid, st) : launch64k_t<16, MODE_TRAIN_BCE>(a, grid, st);
-    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL && mode != MODE_SCORE && mode != MODE_STATS) || a.KB != 32)
+    if ((mode != MODE_TRAIN_BCE && mode != MODE_TRAIN_KL && mode != MODE_SCORE && mode != MODE_STATS && mode != MODE_COUNT) || a.KB != 32)
         return hipErrorInvalidValue;
     if (mode == MODE_SCORE) return launch64k_t<32, MODE_SCORE>(a, grid, st);
+    if (mode == MODE_COUNT) return launch64k_t<32, MODE_COUNT>(a, grid, st);
     if (mode == MODE_STATS) return launch64k_t<32, MODE_STATS>(a, grid, st);
     return mode == MODE_TRAIN_KL ? launch64k_t<32, MODE_TRAIN_KL>(a, grid, st) : launch64k_t<32, MODE_TRAIN_BCE>(a, grid, st);
 }

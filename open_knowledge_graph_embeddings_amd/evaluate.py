@@ -33,7 +33,8 @@ class FusedEvaluator:
     CUs a sweep's 228 tiles leave empty, are filled with the other chains' work without any per-batch cross-stream wait
     (those cost ~10 us each; round 2's first design paid one per batch).  Measured per batch at the FB15k-237 shape:
     1 chain 0.056 ms, 2 chains 0.046, 3 chains 0.043, 4 chains 0.043-0.048.
-    Slot sizes up to 256, eval mode; PipelinedEvaluator (materialised scores) covers the rest."""
+    Slot sizes up to 512 (round 4: above 256 on the register-tile kernel's counting mode), eval mode; PipelinedEvaluator
+    (materialised scores) covers dropout and candidate tables."""
 
     def __init__(self, E, R, scorer, engine=None, run_len=48, two_streams=True, n_streams=None, collect_ranks=False):
         self.E, self.R, self.scorer = E, R, scorer
@@ -117,7 +118,7 @@ class FusedEvaluator:
 
 class PipelinedEvaluator:
     """The evaluation loop on the MATERIALISING path (okge_evaluate_batch: scores into a (B, N) block, then filtered ranks
-    and meters) -- any slot size, dropout, candidate tables; FusedEvaluator is the fast path for slot sizes up to 256 in
+    and meters) -- any slot size, dropout, candidate tables; FusedEvaluator is the path without the score block in
     eval mode.  Batch i runs on stream i % n_streams with that stream's own score block, rank buffer and query workspace:
     independent chains [scores] [ranks] [meters], no cross-stream wait per batch (each costs ~10 us of queue latency on
     this hardware; the first version ordered a scoring and a ranking stream with two events per batch), so the ranking of

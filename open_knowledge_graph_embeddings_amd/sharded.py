@@ -237,7 +237,7 @@ class ShardedEvaluator:
     """Filtered ranks with the candidates sharded like the entity table (compute_metrics' rank rule,
     dataset.py:423-446; exchange plan of SURVEY.md section 8e).
 
-    `ranks()` runs the FUSED counting sweep on this rank's candidates (okge_evaluate_fused_shard; slot sizes up to 256):
+    `ranks()` runs the FUSED counting sweep on this rank's candidates (okge_evaluate_fused_shard; slot sizes up to 512):
         exchange 1   the prefixes' entity rows -> folded queries (all-gather of the owned rows with an ExchangePlan, else
                      all-reduce), as in training
         points       every answer group's true score over the ids this rank holds       -> all-reduce(MAX)  [n_groups] floats
@@ -289,8 +289,6 @@ class ShardedEvaluator:
     def ranks(self, batch: H.PrefixBatch, filt_ptr, filt_col, row_ptr, grp_ptr, ids, plan: ExchangePlan = None):
         """int64 rank per answer group, identical on every rank.  Index arrays are global (positions in the full
         candidate list) and identical on every rank."""
-        if self.E.shape[1] > 256:
-            return self.ranks_materialised(batch, filt_ptr, filt_col, row_ptr, grp_ptr, ids, plan)
         eng = self.engine
         n_groups = int(grp_ptr.numel()) - 1
         dev = self.E.device

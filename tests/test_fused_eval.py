@@ -101,6 +101,24 @@ def test_fused_eval_random(okge_lib, i):
     _check(hp, E, R, scorer, batch, csr, N)
 
 
+@pytest.mark.parametrize("i", range(10))
+def test_fused_eval_wide_slots(okge_lib, i):
+    """slot sizes 257 .. 512 (round 4): the counting mode of the register-tile kernel (fused_tile64k_kernel<count>, stream-K
+    launch, operands swapped) + point scores in that kernel's two-half summation order -- ranks bit-equal to the materialising
+    path, incl. chunks with more groups than the LDS counters hold (the take-turns path), ties, rows without groups, id lists"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    hp = H.HotPath("cuda:0")
+    rng = np.random.default_rng(7000 + i)
+    scorer = "complex" if i % 2 == 0 else "distmult"
+    d = [512, 260, 320, 512, 400, 384, 258, 512, 448, 300][i]
+    n_ent = [2100, 700, 130, 9000, 515, 3000, 67, 1500, 2050, 700][i]
+    n_po, n_sp = [(64, 64), (40, 40), (0, 70), (256, 256), (13, 9), (100, 0), (1, 0), (33, 31), (130, 65), (20, 50)][i]
+    # i == 3: the cfg3 shape of the table (d = 512, B = 512); i == 7: one row with 1700 groups: its chunk overflows the LDS counters
+    E, R, batch, csr, N = _case(rng, n_ent, 30, d, n_po, n_sp, scorer, max_groups=[2, 6, 1, 3][i % 4], ties=i % 3 == 0,
+                                cand_list=i % 5 == 1, many=1700 if i == 7 else (70 if i % 4 == 2 else None))
+    _check(hp, E, R, scorer, batch, csr, N)
+
+
 def test_fused_eval_fb15k237_batch(okge_lib):
     """the real FB15k-237 evaluation batch G10 at the BASELINE size, against the reference's own ranks"""
     from test_fb15k237_batch import check_ranks, tables

@@ -653,6 +653,15 @@ def test_sharded_fused_ranks_emulated_shards(world, okge_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,d", [(2, 320), (3, 512)])
+def test_sharded_fused_ranks_emulated_shards_wide_slots(world, d, okge_lib, monkeypatch):
+    """the same over slot sizes 257 .. 512 (round 4: the counting mode of the register-tile kernel; until then these sizes fell
+    back to a (B, N / world) score block)"""
+    monkeypatch.setattr(sys.modules[__name__], "D", d)
+    test_sharded_fused_ranks_emulated_shards(world, okge_lib)
+
+
+@pytest.mark.gpu
 def test_sharded_step_one_rank_equals_fused_step(okge_lib):
     import torch.distributed as dist
     from open_knowledge_graph_embeddings_amd.sharded import ShardedTrainStep
