@@ -14,7 +14,10 @@ from open_knowledge_graph_embeddings_amd import hotpath as H, synthetic  # noqa:
 from open_knowledge_graph_embeddings_amd.dataset import CollatedBatch  # noqa: E402
 from open_knowledge_graph_embeddings_amd.evaluate import FusedEvaluator, PipelinedEvaluator  # noqa: E402
 
+import dataclasses  # noqa: E402
 w = synthetic.WORKLOADS["S-FB"]
+if os.environ.get("OKGE_EVAL_D"):            # e.g. OKGE_EVAL_D=512 OKGE_EVAL_SCORER=distmult: configs[2]'s table shape
+    w = dataclasses.replace(w, d=int(os.environ["OKGE_EVAL_D"]), scorer=os.environ.get("OKGE_EVAL_SCORER", w.scorer))
 dev = torch.device("cuda:0")
 E, R = synthetic.make_tables(w)
 Et, Rt = torch.from_numpy(E).to(dev), torch.from_numpy(R).to(dev)
