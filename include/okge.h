@@ -276,7 +276,8 @@ typedef struct okge_pool_call {
     float *saved;
     const float *d_out;
     float *dW, *d_bn_weight, *d_bn_bias;
-    uint8_t *row_touched;        /* backward, optional: [vocab] bytes; row_touched[t] = touched_stamp for every row t of dW written */
+    uint8_t *row_touched;        /* optional: [vocab] bytes; backward: row_touched[t] = touched_stamp for every row t of dW written;
+                                    forward (training != 0): for every token row the call reads (padding row 0 included) */
     int32_t touched_stamp;       /* 1..255 (okge_adagrad_multi reads the map with the same stamp) */
     int32_t _pad;
 } okge_pool_call;
@@ -361,7 +362,11 @@ typedef struct okge_adagrad_tensor {
     float *p, *g, *state_sum;
     int64_t n;
     const uint8_t *row_touched;
-    int32_t row_len, touched_stamp, zero_grad, _pad;
+    int32_t row_len, touched_stamp, zero_grad;
+    int32_t rows;                /* 0: all rows; 1: only the rows WITHOUT the stamp (weight-decay-only update, the gradient is not read);
+                                    2: only the rows WITH the stamp.  1 then 2 = 0, row for row: the rows no token of the batch names can
+                                    take their update while the step's matrix kernels run (okge_pool_encode_calls stamps the rows the
+                                    forward reads, so the sweep of the others may start right behind it on another stream) */
 } okge_adagrad_tensor;
 int okge_adagrad_multi(const okge_adagrad_tensor *tensors, int32_t n_tensors, float lr, float weight_decay, float eps,
                        void *stream);

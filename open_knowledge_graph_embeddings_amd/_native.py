@@ -97,7 +97,7 @@ class AdagradOpt(Structure):
 
 class AdagradTensor(Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("state_sum", c_void_p), ("n", c_int64), ("row_touched", c_void_p),
-                ("row_len", c_int32), ("touched_stamp", c_int32), ("zero_grad", c_int32), ("_pad", c_int32)]
+                ("row_len", c_int32), ("touched_stamp", c_int32), ("zero_grad", c_int32), ("rows", c_int32)]
 
 
 class PrefixTable(Structure):

@@ -1000,6 +1000,10 @@ static int pool_call_dev(const okge_pool_call &c, bool backward, bool training, 
         if (bn && training && !c.saved)
             return fail(OKGE_ERR_INVALID, "training-mode batch-norm needs the saved-statistics buffer (4*d floats)");
         q.saved = bn && training ? c.saved : nullptr;
+        if (training && c.row_touched) {                    // forward in training mode: every token row the call READS is stamped
+            if (c.touched_stamp < 1 || c.touched_stamp > 255) return fail(OKGE_ERR_INVALID, "touched_stamp must lie in 1..255");
+            q.touched = c.row_touched; q.touched_stamp = c.touched_stamp;
+        }
     } else {
         if (!c.d_out || !c.dW) return fail(OKGE_ERR_INVALID, "bad backward arguments");
         if (bn && (!c.saved || !c.d_bn_weight || !c.d_bn_bias))
@@ -1181,7 +1185,8 @@ int okge_adagrad_multi(const okge_adagrad_tensor *tensors, int32_t n_tensors, fl
             if (t.touched_stamp < 1 || t.touched_stamp > 255) return fail(OKGE_ERR_INVALID, "touched_stamp must lie in 1..255");
             if (!t.zero_grad) return fail(OKGE_ERR_INVALID, "a touched-row map needs zero_grad (rows not stamped must hold zero gradients)");
         }
-        segs[i] = AdagradSegM{t.p, t.g, t.state_sum, t.n, t.row_touched, t.row_len, t.touched_stamp, t.zero_grad, 0};
+        if (t.rows < 0 || t.rows > 2 || (t.rows && !t.row_touched)) return fail(OKGE_ERR_INVALID, "rows: 0 all, 1 unstamped only, 2 stamped only (1 / 2 need a map)");
+        segs[i] = AdagradSegM{t.p, t.g, t.state_sum, t.n, t.row_touched, t.row_len, t.touched_stamp, t.zero_grad, t.rows};
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     ScopedTimer tm("adagrad", st);

@@ -183,7 +183,7 @@ hipError_t launch_pool_backward_calls(const PoolCall *calls, int n_calls, int *i
 // dense Adagrad over up to four tensors in one launch; a tensor may come with a touched-row byte map (rows whose byte differs
 // from `stamp` hold an all-zero gradient by contract: it is neither read nor cleared)
 constexpr int ADAGRAD_MAX_SEGS = 4;
-struct AdagradSegM { float *p, *g, *s; int64_t n; const uint8_t *touched; int32_t row_len, stamp, zero_grad, _pad; };
+struct AdagradSegM { float *p, *g, *s; int64_t n; const uint8_t *touched; int32_t row_len, stamp, zero_grad, rows; };   // rows: 0 all, 1 unstamped only, 2 stamped only
 hipError_t launch_adagrad_multi(const AdagradSegM *segs, int n_segs, float lr, float wd, float eps, hipStream_t st);
 hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
                             int cand_first, int exclusive, int grads_zero, float *dE, int64_t table_rows, int *id_err,

@@ -794,7 +794,11 @@ __device__ __forceinline__ void adagrad_sweep_map(const AdagradSegM sg, float lr
             if (MAP) mb[u] = sg.touched[shift >= 0 ? (uint32_t)i >> shift : (uint32_t)i / row4];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) live[u] = ok[u] && mb[u] == stamp;
+        for (int u = 0; u < U; ++u) {
+            live[u] = ok[u] && mb[u] == stamp;
+            if (MAP && sg.rows == 1) { ok[u] = ok[u] && !live[u]; live[u] = false; }     // unstamped rows only (never a gradient read)
+            if (MAP && sg.rows == 2) ok[u] = live[u];                                     // stamped rows only
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
@@ -830,6 +834,44 @@ __device__ __forceinline__ void adagrad_sweep_map(const AdagradSegM sg, float lr
         sg.s[i] = fmaf(gj, gj, sg.s[i]);
         sg.p[i] = sg.p[i] - lr * (gj / (sqrtf(sg.s[i]) + eps));
         if (sg.zero_grad) sg.g[i] = 0.f;
+    }
+}
+
+// rows == 1 on its own launch: the weight-decay-only update of the rows WITHOUT the stamp, built to run BESIDE the step's matrix
+// kernels on another stream -- one-wave workgroups and few registers, so that a wave fits the register file the fused tile
+// kernel leaves over (230 x 2 of 512 per SIMD at d = 256); two rows in flight per lane
+__global__ __launch_bounds__(64) void adagrad_unstamped_kernel(const AdagradSegsDev segs, float lr, float wd, float eps)
+{
+    const int64_t first = (int64_t)blockIdx.x * 64 + threadIdx.x, stride = (int64_t)gridDim.x * 64;
+    for (int k = 0; k < segs.n; ++k) {
+        const AdagradSegM sg = segs.s[k];
+        if (!sg.touched || sg.rows != 1) continue;
+        const int64_t n4 = sg.n >> 2;
+        float4 *p4 = reinterpret_cast<float4 *>(sg.p), *s4 = reinterpret_cast<float4 *>(sg.s);
+        const uint32_t row4 = (uint32_t)(sg.row_len >> 2);
+        const int shift = (row4 & (row4 - 1)) == 0 ? 31 - __clz(row4) : -1;
+        const uint8_t stamp = (uint8_t)sg.stamp;
+        for (int64_t i0 = first; i0 < n4; i0 += 2 * stride) {
+            const int64_t i1 = i0 + stride;
+            const bool ok1 = i1 < n4;
+            const uint8_t m0 = sg.touched[shift >= 0 ? (uint32_t)i0 >> shift : (uint32_t)i0 / row4];
+            const uint8_t m1 = ok1 ? sg.touched[shift >= 0 ? (uint32_t)i1 >> shift : (uint32_t)i1 / row4] : stamp;
+            float4 pa = p4[i0], sa = s4[i0], pb = pa, sb = sa;
+            if (ok1) { pb = p4[i1]; sb = s4[i1]; }
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 != stamp) {
+                const float4 po = pa, so = sa;
+                adagrad4(pa, zero, sa, lr, wd, eps);
+                if (bits_differ(pa, po)) p4[i0] = pa;
+                if (bits_differ(sa, so)) s4[i0] = sa;
+            }
+            if (ok1 && m1 != stamp) {
+                const float4 po = pb, so = sb;
+                adagrad4(pb, zero, sb, lr, wd, eps);
+                if (bits_differ(pb, po)) p4[i1] = pb;
+                if (bits_differ(sb, so)) s4[i1] = sb;
+            }
+        }
     }
 }
 
@@ -1355,6 +1397,13 @@ hipError_t launch_adagrad_multi(const AdagradSegM *segs, int n_segs, float lr, f
         n4 = std::max(n4, (segs[k].n + 3) / 4);
     }
     if (n4 <= 0) return hipSuccess;
+    bool all_unstamped = true;
+    for (int k = 0; k < n_segs; ++k) all_unstamped = all_unstamped && segs[k].rows == 1 && segs[k].touched;
+    if (all_unstamped) {                                 // the lean kernel that runs beside the matrix kernels
+        const int blocks = (int)std::min((int64_t)32768, (n4 + 127) / 128);
+        hipLaunchKernelGGL(adagrad_unstamped_kernel, dim3(blocks), dim3(64), 0, st, a, lr, wd, eps);
+        return hipGetLastError();
+    }
     const int blocks = (int)std::min((int64_t)16384, (n4 + 255) / 256);
     hipLaunchKernelGGL(adagrad_multi_kernel, dim3(blocks), dim3(256), 0, st, a, lr, wd, eps);
     return hipGetLastError();

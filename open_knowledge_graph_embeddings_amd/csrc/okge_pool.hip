@@ -259,6 +259,11 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const PoolBatch pb, int
     for (int i = threadIdx.x; i < nr * L; i += blockDim.x)
         toks[i / L][i % L] = q.tokens[(size_t)row_id(q.ids, q.first_id, r0 + i / L, q.n_ids, (i % L) ? nullptr : pb.id_err) * L + i % L];
     __syncthreads();
+    if (training && q.touched)                           // every token row this call reads (row 0 of the padded positions too)
+        for (int i = threadIdx.x; i < nr * L; i += blockDim.x) {
+            const int tok = toks[i / L][i % L];
+            if ((unsigned)tok < (unsigned)q.vocab) q.touched[tok] = (uint8_t)q.touched_stamp;
+        }
     if (threadIdx.x < nr) {
         int len = 0;
         for (int t = 0; t < L; ++t) len += toks[threadIdx.x][t] > 0;

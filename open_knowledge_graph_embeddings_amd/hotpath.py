@@ -459,7 +459,7 @@ class HotPath:
                                             float(eps), int(zero_grad), self._stream()), "okge_adagrad_step2")
 
     def adagrad_multi(self, tensors, lr, weight_decay=1e-10, eps=1e-8):
-        """One launch over up to four (p, g, state_sum[, touched_map, stamp]) tuples, gradients cleared in the sweep
+        """One launch over up to four (p, g, state_sum[, touched_map, stamp[, rows]]) tuples, gradients cleared in the sweep
         (okge_adagrad_multi): a tensor with a touched-row byte map skips the gradient rows the map does not stamp."""
         arr = (N.AdagradTensor * len(tensors))()
         for a, t in zip(arr, tensors):
@@ -467,6 +467,7 @@ class HotPath:
             a.p, a.g, a.state_sum, a.n, a.zero_grad = p.data_ptr(), g.data_ptr(), s.data_ptr(), p.numel(), 1
             if len(t) > 3 and t[3] is not None:
                 a.row_touched, a.row_len, a.touched_stamp = t[3].data_ptr(), p.shape[1], int(t[4])
+                a.rows = int(t[5]) if len(t) > 5 else 0          # 0 all rows, 1 the unstamped rows only, 2 the stamped rows only
         N.check(self.lib.okge_adagrad_multi(arr, len(tensors), float(lr), float(weight_decay), float(eps), self._stream()),
                 "okge_adagrad_multi")
 

@@ -126,7 +126,7 @@ class PoolEngine:
 
 
     # -- a batch of _encode calls in one go (okge_pool_encode_calls / okge_pool_backward_calls) ----------------------
-    def _calls(self, calls, backward):
+    def _calls(self, calls, backward, stamp_forward=False):
         """calls: [(slot, ids, first_id, n, raw, out_or_d_out, saved)] with n > 0 -> (ctypes array, keep-alive list)"""
         arr = (N.PoolCall * len(calls))()
         keep, need = [], 0
@@ -146,6 +146,8 @@ class PoolEngine:
                     x.row_touched, x.touched_stamp = touched.data_ptr(), int(slot.stamp)
             else:
                 x.out = other.data_ptr()
+                if stamp_forward and getattr(slot, "touched", None) is not None:      # the forward stamps every token row it reads
+                    x.row_touched, x.touched_stamp = slot.touched.data_ptr(), int(slot.stamp)
             need += int(self.lib.okge_pool_workspace_bytes(int(n), slot.d))
         if backward and self.scatter_plan(calls):
             need = int(self.lib.okge_pool_backward_workspace_bytes(arr, len(calls)))
@@ -165,11 +167,11 @@ class PoolEngine:
             return False
         return all(c[0].pool != "max" and c[0].d % 4 == 0 for c in calls)
 
-    def encode_calls(self, calls, training):
+    def encode_calls(self, calls, training, stamp=False):
         calls = [c for c in calls if c[3] > 0]
         if not calls:
             return
-        arr, keep = self._calls(calls, False)
+        arr, keep = self._calls(calls, False, stamp_forward=stamp and training)
         N.check(self.lib.okge_pool_encode_calls(arr, len(calls), int(training), None if self._ws is None else self._ws.data_ptr(),
                                                 self._ws_bytes, self._stream()), "okge_pool_encode_calls")
         del keep
@@ -195,8 +197,20 @@ class TokenPooledTrainStep:
     (Trainer.compute_one_batch, trainer.py:181-257, over model.py:762-796)."""
 
     def __init__(self, entity: TokenSlot, relation: TokenSlot, scorer, loss="bce", lr=0.1, weight_decay=1e-10, eps=1e-8,
-                 label_smoothing=0.0, dropout=0.0, seed=0, engine=None):
+                 label_smoothing=0.0, dropout=0.0, seed=0, engine=None, overlap_sweep=None):
         self.entity, self.relation, self.scorer, self.loss = entity, relation, scorer, loss
+        # overlap_sweep (OKGE_OVERLAP_SWEEP=1; an experiment, OFF by default): the Adagrad update of the token rows NO token of the
+        # batch names (85 % of them at configs[4]; the reference's weight decay reaches every row: 0.9 GB of read-modify-write per
+        # step) on a side stream BESIDE the step's matrix kernels -- the pooling forward stamps the rows it reads, so the others are
+        # known right behind it and nothing of the step reads or writes them.  Same arithmetic row for row (rows = 1 then rows = 2
+        # of okge_adagrad_multi; bit-equal tables: test_overlapped_sweep_is_bit_equal_to_the_plain_step).  Measured at configs[4]:
+        # the late sweep shrinks 178 -> ~25 us, but the fused tile kernel beside the side sweep stretches 292 -> 398 us and the
+        # encode launch 15 -> 43 us: 0.826 -> 0.852 ms cold, 0.725 -> 0.763 warm -- a loss (fp32 MFMA shares the SIMD's issue
+        # with the sweep's sqrt / div VALU work, profiles/round4_ablation.md section 5), like the S-FB attempt of round 2.
+        if overlap_sweep is None:
+            overlap_sweep = os.environ.get("OKGE_OVERLAP_SWEEP", "0") == "1"
+        self.overlap_sweep = bool(overlap_sweep)
+        self._side, self._side_done = None, None
         self.lr, self.weight_decay, self.eps, self.label_smoothing = lr, weight_decay, eps, label_smoothing
         self.dropout, self.seed, self.steps = dropout, seed, 0
         self.device = entity.W.device
@@ -267,7 +281,11 @@ class TokenPooledTrainStep:
 
     def step(self, batch: H.PrefixBatch, normalizer=None):
         """`batch` carries ENTITY / RELATION ids exactly as for the lookup models."""
-        loss = self.forward_backward(batch, normalizer)
+        self._in_step = True
+        try:
+            loss = self.forward_backward(batch, normalizer)
+        finally:
+            self._in_step = False
         self.optimizer_step()
         return loss
 
@@ -289,7 +307,26 @@ class TokenPooledTrainStep:
                  (rel, _i32(batch.sp_rel, dev), 0, n_sp, RX[n_po:B], RV[n_po:B], dRV[n_po:B], sv[4] if bn_r else None)]
         # forward of all five calls: raw pooled rows -> EX / RX, batch-normed rows -> EV / RV (per-call statistics, running
         # statistics updated in this order)
-        pe.encode_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]) for c_ in calls], True)
+        # (only inside step(): a caller that runs forward_backward alone -- the autograd bridge, ReplicaStep, whose other replicas'
+        #  rows receive gradients in the exchange -- gets no early update)
+        overlap = (self.overlap_sweep and getattr(self, "_in_step", False) and ent.touched is not None and rel.touched is not None
+                   and not torch.cuda.is_current_stream_capturing())
+        if self._side_done is not None:            # the previous step's side sweep wrote rows this forward may read
+            torch.cuda.current_stream(dev).wait_event(self._side_done)
+            self._side_done = None
+        pe.encode_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]) for c_ in calls], True,
+                        stamp=overlap)
+        self._early_swept = False
+        if overlap:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            self._side.wait_event(main.record_event())       # the maps are complete: every row without the stamp is free
+            with torch.cuda.stream(self._side):
+                self.engine.adagrad_multi([(sl.W, sl.dW, sl.sumW, sl.touched, sl.stamp, 1) for sl in (ent, rel)],
+                                          self.lr, self.weight_decay, self.eps)
+                self._side_done = self._side.record_event()
+            self._early_swept = True
         EVt, RVt = (EV if bn_e else EX), (RV if bn_r else RX)
         # the fused step on the virtual tables: candidates are rows 0..N-1, prefix entities follow
         # row indices of the virtual tables: they depend on the batch's shape only -- built once per shape (four arange
@@ -323,8 +360,11 @@ class TokenPooledTrainStep:
     def optimizer_step(self):
         eng, e, r = self.engine, self.entity, self.relation
         # one launch: token tables (gradient rows the backward did not stamp are neither read nor cleared) + batch-norm parameters
-        tensors = [(sl.W, sl.dW, sl.sumW, sl.touched, sl.stamp) for sl in (e, r)]
+        # (after an early sweep of the unstamped rows -- forward_backward, overlap_sweep -- only the stamped rows are left)
+        rows = 2 if getattr(self, "_early_swept", False) else 0
+        tensors = [(sl.W, sl.dW, sl.sumW, sl.touched, sl.stamp, rows) for sl in (e, r)]
         tensors += [(sl.bn, sl.d_bn, sl.sum_bn) for sl in (e, r) if sl.bn is not None]
+        self._early_swept = False
         eng.adagrad_multi(tensors, self.lr, self.weight_decay, self.eps)
         for sl in (e, r):
             sl.next_stamp()

@@ -199,6 +199,8 @@ class GraphedTrainStep:
             cand_first=example.cand_first, n_cand=example.n_cand, cand_unique=example.cand_unique)
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev) if counter is None else counter
         inner.step_dev = self.counter
+        if getattr(inner, "overlap_sweep", False):
+            inner.overlap_sweep = False         # (token-pooled step: the side-stream sweep is a launch-time arrangement, not captured)
         self.normalizer = normalizer
         self._load(example)
         state = inner.state_tensors()

@@ -292,3 +292,41 @@ def test_touched_map_adagrad_is_bit_equal_to_the_dense_sweep(okge_lib):
     for x, y in ((a[1], b_[1]), (a[2], b_[2])):
         assert torch.equal(x.W, y.W) and torch.equal(x.sumW, y.sumW) and torch.equal(x.bn, y.bn)
         assert float(x.dW.abs().max()) == 0.0                    # cleared where stamped, zero elsewhere
+
+
+def test_overlapped_sweep_is_bit_equal_to_the_plain_step(okge_lib):
+    """overlap_sweep: the update of the token rows no token of the batch names runs on a side stream beside the step's matrix
+    kernels (rows = 1 of okge_adagrad_multi right behind the pooling forward, rows = 2 after the backward) -- same arithmetic
+    row for row: tables, accumulators, batch-norm parameters and losses bit-equal to the step without it, over several steps
+    with DIFFERENT batches (the next forward must wait for the side sweep of the step before)"""
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch, positives_from_dense
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    rng = np.random.default_rng(21)
+    c = _plan_case(rng, d=64, L=6, n_ent=2000, vt_e=5000, N=900, n_po=96, n_sp=96, bn=True, mid_tokens=(45,))
+
+    def make(overlap):
+        bn = c["bn_e"]
+        e = TokenSlot(dev(c["We"]), dev(c["ent_tok"]), "sum", True, dev(bn["weight"]), dev(bn["bias"]))
+        r = TokenSlot(dev(c["Wr"]), dev(c["rel_tok"]), "sum", True, dev(c["bn_r"]["weight"]), dev(c["bn_r"]["bias"]))
+        return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=0.1, seed=3, overlap_sweep=overlap), e, r
+    a, b_ = make(True), make(False)
+    assert a[0].overlap_sweep and not b_[0].overlap_sweep
+    r2 = np.random.default_rng(5)
+    for step in range(6):
+        N, B = 900, 192
+        y = np.zeros((B, N), np.float32)
+        y[np.arange(B), r2.integers(0, N, B)] = 1
+        mk = lambda: PrefixBatch(cand_ids=dev(r2_c), po_rel=dev(pr), po_obj=dev(po), sp_subj=dev(ss), sp_rel=dev(sr))   # noqa: E731
+        r2_c = r2.integers(2, 2000, N).astype(np.int32)
+        pr, po = r2.integers(2, 40, B // 2).astype(np.int32), r2.integers(2, 2000, B // 2).astype(np.int32)
+        ss, sr = r2.integers(2, 2000, B // 2).astype(np.int32), r2.integers(2, 40, B // 2).astype(np.int32)
+        losses = []
+        for st, _, _ in (a, b_):
+            bt = mk()
+            bt.pos_row, bt.pos_col = positives_from_dense(dev(y))
+            losses.append(float(st.step(bt)[0]))
+        assert losses[0] == losses[1], (step, losses)
+    torch.cuda.synchronize()
+    for x, y_ in ((a[1], b_[1]), (a[2], b_[2])):
+        assert torch.equal(x.W, y_.W) and torch.equal(x.sumW, y_.sumW) and torch.equal(x.bn, y_.bn) and torch.equal(x.sum_bn, y_.sum_bn)
+        assert float(x.dW.abs().max()) == 0.0
