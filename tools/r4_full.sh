@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4
 mkdir -p $O
 cd $R
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/full.log 2>&1; echo "tests rc=$?" >> $O/full.log
+timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/full.log 2>&1; echo "tests rc=$?" >> $O/full.log
 tail -12 $O/full.log
 timeout -k 10 400 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 python - <<'PY'
