@@ -371,6 +371,36 @@ typedef struct okge_adagrad_tensor {
 int okge_adagrad_multi(const okge_adagrad_tensor *tensors, int32_t n_tensors, float lr, float weight_decay, float eps,
                        void *stream);
 
+/* ---- dense Adagrad with the weight-decay-only updates deferred ("lazy decay") ---------------------------------------------
+ * The reference's optimizer reaches EVERY row of a table in every step: with weight_decay != 0 (1e-10 in all its configs)
+ * even a row no gradient reached moves by its own decay term (utils/optim.py:139-160, dense gradients).  For a token table
+ * that is most rows (85 % at BASELINE configs[4]): a read-modify-write of the whole table and its accumulator per step.
+ * Such an update depends on that row's (p, state_sum) alone, so it can be applied later -- all pending steps at once, in
+ * registers, the same operations in the same order -- provided it has happened before anything READS the row:
+ *   row_steps[r]    optimizer steps row r has seen;  counters[0] = steps taken (T),  counters[1] = scratch (both start 0)
+ *   okge_pool_catch_up_calls   before the pooling forward: the rows the batch's tokens name are brought to T
+ *   okge_adagrad_lazy(OKGE_LAZY_STEP)   rows carrying touched_stamp: their pending steps, then this step with their
+ *                   gradient (cleared; the map byte goes back to 0); rows with r % window == T % window: their pending
+ *                   steps and this one; tensors without row_steps (batch-norm parameters): every element; then T += 1
+ *   okge_adagrad_lazy(OKGE_LAZY_FLUSH)  every row to T -- before evaluation, checkpoints or any other reader of the tables
+ * After a flush the tables are BIT-IDENTICAL to window = 1, i.e. to okge_adagrad_multi / the reference's order of
+ * operations.  lr, weight_decay and eps must not change while steps are pending (flush first).  T lives on the device so
+ * that a captured HIP graph replays correctly. */
+#define OKGE_LAZY_STEP 0
+#define OKGE_LAZY_FLUSH 1
+typedef struct okge_lazy_tensor {
+    float *p, *g, *state_sum;    /* (rows, row_len) */
+    int64_t rows;
+    int32_t *row_steps;          /* [rows], or NULL: a plain dense tensor of rows * row_len floats, updated every step */
+    uint8_t *row_touched;        /* [rows] map the pooling backward stamps (okge_pool_call.row_touched), or NULL */
+    int32_t row_len, touched_stamp;
+} okge_lazy_tensor;
+int okge_adagrad_lazy(const okge_lazy_tensor *tensors, int32_t n_tensors, int32_t *counters, int32_t window, int32_t mode, float lr,
+                      float weight_decay, float eps, void *stream);
+/* calls: the batch's okge_pool_encode_calls list; tables: the lazy tensors (matched to a call by p == e->W) */
+int okge_pool_catch_up_calls(const okge_pool_call *calls, int32_t n_calls, const okge_lazy_tensor *tables, int32_t n_tables,
+                             const int32_t *counters, float lr, float weight_decay, float eps, void *stream);
+
 /* ---- the whole step in one call: okge_train_forward_backward + the dense Adagrad update of both tables ------------------
  * (Trainer.compute_one_batch's training branch end to end, trainer.py:217-257 with utils/optim.py:139-160.)  Same arithmetic,
  * element for element, as okge_train_forward_backward followed by okge_adagrad_step2(zero_grad = 2 or 1) -- tables and

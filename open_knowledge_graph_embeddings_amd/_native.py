@@ -32,7 +32,7 @@ LOSSES = {"bce": OKGE_LOSS_BCE, "kl": OKGE_LOSS_KL}
 EXPORTS = ["okge_abi_version", "okge_last_error", "okge_score_prefixes", "okge_train_forward_backward",
            "okge_train_workspace_bytes", "okge_score_workspace_bytes", "okge_lse_workspace_bytes", "okge_query_ld", "okge_query_rows", "okge_encode_queries", "okge_train_tiles",
            "okge_prefix_backward", "okge_prefix_backward_segmented", "okge_fold_queries", "okge_score_queries", "okge_row_logsumexp", "okge_group_true_scores",
-           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_shard", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward", "okge_pool_encode_calls", "okge_pool_backward_calls", "okge_pool_scatter_state_bytes", "okge_pool_backward_workspace_bytes", "okge_adagrad_multi", "okge_train_step", "okge_prefix_score_backward", "okge_prefix_score_backward_workspace_bytes", "okge_scatter_rows",
+           "okge_rank_counts", "okge_rank_metrics", "okge_evaluate_batch", "okge_evaluate_fused", "okge_evaluate_fused_shard", "okge_evaluate_fused_batches", "okge_eval_workspace_bytes", "okge_score_triples", "okge_pool_workspace_bytes", "okge_pool_encode", "okge_pool_backward", "okge_pool_encode_calls", "okge_pool_backward_calls", "okge_pool_scatter_state_bytes", "okge_pool_backward_workspace_bytes", "okge_adagrad_multi", "okge_adagrad_lazy", "okge_pool_catch_up_calls", "okge_train_step", "okge_prefix_score_backward", "okge_prefix_score_backward_workspace_bytes", "okge_scatter_rows",
            "okge_collate_batch", "okge_collate_batches", "okge_dataset_open", "okge_dataset_sizes",
            "okge_dataset_copy", "okge_dataset_close", "okge_encode_rows", "okge_scale_inplace", "okge_rescale_gradients", "okge_adagrad_step", "okge_adagrad_step2", "okge_id_errors", "okge_clip_grad_norm", "okge_merge_logsumexp", "okge_filtered_ranks", "okge_timing_enable",
            "okge_timing_reset", "okge_timing_collect"]
@@ -98,6 +98,11 @@ class AdagradOpt(Structure):
 class AdagradTensor(Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("state_sum", c_void_p), ("n", c_int64), ("row_touched", c_void_p),
                 ("row_len", c_int32), ("touched_stamp", c_int32), ("zero_grad", c_int32), ("rows", c_int32)]
+
+
+class LazyTensor(Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("state_sum", c_void_p), ("rows", c_int64), ("row_steps", c_void_p),
+                ("row_touched", c_void_p), ("row_len", c_int32), ("touched_stamp", c_int32)]
 
 
 class PrefixTable(Structure):
@@ -286,6 +291,10 @@ def lib():
                                   c_double, c_int32, POINTER(AdagradOpt), c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
     L.okge_adagrad_multi.restype = c_int32
     L.okge_adagrad_multi.argtypes = [POINTER(AdagradTensor), c_int32, c_float, c_float, c_float, c_void_p]
+    L.okge_adagrad_lazy.restype = c_int32
+    L.okge_adagrad_lazy.argtypes = [POINTER(LazyTensor), c_int32, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_void_p]
+    L.okge_pool_catch_up_calls.restype = c_int32
+    L.okge_pool_catch_up_calls.argtypes = [POINTER(PoolCall), c_int32, POINTER(LazyTensor), c_int32, c_void_p, c_float, c_float, c_float, c_void_p]
     L.okge_scale_inplace.restype = c_int32
     L.okge_scale_inplace.argtypes = [c_void_p, c_int64, c_void_p, c_void_p]
     L.okge_rescale_gradients.restype = c_int32

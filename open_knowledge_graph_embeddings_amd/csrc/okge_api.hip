@@ -1195,6 +1195,66 @@ int okge_adagrad_multi(const okge_adagrad_tensor *tensors, int32_t n_tensors, fl
     return OKGE_OK;
 }
 
+static int lazy_tensor_dev(const okge_lazy_tensor &t, LazySeg &sg)
+{
+    if (!t.p || !t.g || !t.state_sum || t.rows < 0 || t.row_len <= 0) return fail(OKGE_ERR_INVALID, "bad lazy adagrad tensor");
+    if (t.row_steps) {
+        if (t.row_len % 4 || t.rows > INT32_MAX) return fail(OKGE_ERR_INVALID, "deferred rows need a row length that is a multiple of 4 and fewer than 2^31 rows");
+        if ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.state_sum)) % 16)
+            return fail(OKGE_ERR_INVALID, "adagrad buffers must be 16-byte aligned");
+        if (t.row_touched && (t.touched_stamp < 1 || t.touched_stamp > 255)) return fail(OKGE_ERR_INVALID, "touched_stamp must lie in 1..255");
+    } else if (t.row_touched) return fail(OKGE_ERR_INVALID, "a touched-row map needs row_steps");
+    sg = LazySeg{t.p, t.g, t.state_sum, t.row_steps, t.row_touched, t.rows, t.row_len, t.touched_stamp};
+    return OKGE_OK;
+}
+
+int okge_adagrad_lazy(const okge_lazy_tensor *tensors, int32_t n_tensors, int32_t *counters, int32_t window, int32_t mode, float lr,
+                      float weight_decay, float eps, void *stream)
+{
+    if (!tensors || n_tensors <= 0 || n_tensors > ADAGRAD_MAX_SEGS) return fail(OKGE_ERR_INVALID, "1 to 4 tensors per adagrad launch");
+    if (!counters || window < 1 || (mode != OKGE_LAZY_STEP && mode != OKGE_LAZY_FLUSH))
+        return fail(OKGE_ERR_INVALID, "okge_adagrad_lazy needs the counters, window >= 1 and mode OKGE_LAZY_STEP / OKGE_LAZY_FLUSH");
+    LazySeg segs[ADAGRAD_MAX_SEGS];
+    for (int i = 0; i < n_tensors; ++i)
+        if (int rc = lazy_tensor_dev(tensors[i], segs[i])) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm(mode == OKGE_LAZY_STEP ? "adagrad" : "adagrad_flush", st);
+    hipError_t e = launch_adagrad_lazy(segs, n_tensors, counters, window, mode, lr, weight_decay, eps, st);
+    if (e != hipSuccess) return fail_hip(e, "adagrad_lazy");
+    return OKGE_OK;
+}
+
+int okge_pool_catch_up_calls(const okge_pool_call *calls, int32_t n_calls, const okge_lazy_tensor *tables, int32_t n_tables,
+                             const int32_t *counters, float lr, float weight_decay, float eps, void *stream)
+{
+    if (!calls || n_calls <= 0 || n_calls > POOL_MAX_CALLS) return fail(OKGE_ERR_INVALID, "1 to 8 pooled calls per batch");
+    if (!tables || n_tables <= 0 || n_tables > ADAGRAD_MAX_SEGS || !counters) return fail(OKGE_ERR_INVALID, "bad catch-up arguments");
+    PoolCall q[POOL_MAX_CALLS];
+    int nq = 0;
+    for (int i = 0; i < n_calls; ++i) {
+        const okge_token_embedder *e = calls[i].e;
+        if (int rc = check_token_embedder(e, calls[i].ids, calls[i].first_id, calls[i].n)) return rc;
+        if (calls[i].n <= 0) return fail(OKGE_ERR_INVALID, "a pooled call needs n > 0 (leave empty calls out of the batch)");
+        for (int j = 0; j < n_tables; ++j) {
+            if (tables[j].p != e->W || !tables[j].row_steps) continue;
+            LazySeg sg;
+            if (int rc = lazy_tensor_dev(tables[j], sg)) return rc;
+            if (tables[j].rows != e->vocab || tables[j].row_len != e->d) return fail(OKGE_ERR_INVALID, "lazy tensor and token table differ in shape");
+            PoolCall &c = q[nq++];
+            std::memset(&c, 0, sizeof(c));
+            c.W = e->W; c.tokens = e->token_ids; c.ids = calls[i].ids; c.d = e->d; c.L = e->max_len; c.first_id = calls[i].first_id;
+            c.n = calls[i].n; c.n_ids = e->n_ids; c.vocab = e->vocab; c.sumW = sg.s; c.steps = sg.steps;
+            break;
+        }
+    }
+    if (!nq) return OKGE_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ScopedTimer tm("pool_catch_up", st);
+    hipError_t err = launch_pool_catch_up(q, nq, counters, lr, weight_decay, eps, id_err_ptr(), st);
+    if (err != hipSuccess) return fail_hip(err, "pool_catch_up");
+    return OKGE_OK;
+}
+
 int okge_filtered_ranks(const float *scores, int64_t ld_scores, int32_t B, int32_t N, const int64_t *filt_ptr,
                         const int32_t *filt_col, const int64_t *row_ptr, const int64_t *grp_ptr, const int32_t *ids,
                         int64_t *ranks, void *stream)

@@ -172,6 +172,107 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t *__restrict__ a, in
     return lo;
 }
 
+// ---- Adagrad arithmetic shared by every kernel that applies it (utils/optim.py:139-160 / torch.optim.Adagrad) -----------------
+__device__ __forceinline__ bool bits_differ(const float4 &a, const float4 &b)
+{
+    return ((__float_as_uint(a.x) ^ __float_as_uint(b.x)) | (__float_as_uint(a.y) ^ __float_as_uint(b.y)) |
+            (__float_as_uint(a.z) ^ __float_as_uint(b.z)) | (__float_as_uint(a.w) ^ __float_as_uint(b.w))) != 0u;
+}
+
+__device__ __forceinline__ void adagrad4(float4 &pv, const float4 &gv, float4 &sv, float lr, float wd, float eps)
+{
+    float *pp = &pv.x, *ss = &sv.x;
+    const float *gg = &gv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // the arithmetic of adagrad_sweep, element for element
+        const float gj = fmaf(wd, pp[j], gg[j]);
+        ss[j] = fmaf(gj, gj, ss[j]);
+        pp[j] = pp[j] - lr * (gj / (sqrtf(ss[j]) + eps));
+    }
+}
+
+// `n` consecutive updates of a row no gradient reached (g = 0: the weight-decay term alone, okge_adagrad_lazy): the same
+// arithmetic as n sweeps, one after the other.  If the first step returns the bits it was given on every active lane of the wave
+// (warm accumulators: wd * p is below half an ulp of both), all later ones do too and are skipped.
+__device__ __forceinline__ void decay_replay4(float4 &pv, float4 &sv, int n, float lr, float wd, float eps)
+{
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n <= 0) return;
+    const float4 p0 = pv, s0 = sv;
+    adagrad4(pv, zero, sv, lr, wd, eps);
+    if (!__any(bits_differ(pv, p0) || bits_differ(sv, s0))) return;      // (checked once: a row that moves keeps moving)
+    for (int i = 1; i < n; ++i) adagrad4(pv, zero, sv, lr, wd, eps);
+}
+
+// The rows a wave owes work on, one after the other with the NEXT row's loads in flight while the current one is replayed
+// (a row is a dependent chain: counters -> row loads -> up to `window` correctly rounded sqrt / div steps -> stores; one row at a
+// time left the wave waiting on HBM for most of its life).  Lane-held description of the wave's 64 candidate rows: `mask` (bit j:
+// lane j's row needs work), row index, pending decay-only steps, and whether the step with the gradient follows.  Rows of up to
+// 256 floats (lane = column quad); longer rows go through the plain column loop.
+__device__ __forceinline__ void lazy_rows(uint64_t mask, int64_t row, int n_decay, bool with_grad, float *__restrict__ p,
+                                          float *__restrict__ s, float *__restrict__ g, int row_len, int lane, float lr, float wd,
+                                          float eps)
+{
+    const int row4 = row_len >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(p), *s4 = reinterpret_cast<float4 *>(s), *g4 = reinterpret_cast<float4 *>(g);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row4 > 64) {
+        while (mask) {
+            const int j = __ffsll((unsigned long long)mask) - 1;
+            mask &= mask - 1;
+            const size_t base = (size_t)__shfl(row, j) * row4;
+            const int n = __shfl(n_decay, j);
+            const bool wg = __shfl((int)with_grad, j) != 0;
+            for (int c = lane; c < row4; c += 64) {
+                float4 pv = p4[base + c], sv = s4[base + c], gv = wg ? g4[base + c] : zero;
+                const float4 p0 = pv, s0 = sv;
+                decay_replay4(pv, sv, n, lr, wd, eps);
+                if (wg) adagrad4(pv, gv, sv, lr, wd, eps);
+                if (bits_differ(pv, p0)) p4[base + c] = pv;
+                if (bits_differ(sv, s0)) s4[base + c] = sv;
+                if (wg && ((__float_as_uint(gv.x) | __float_as_uint(gv.y) | __float_as_uint(gv.z) | __float_as_uint(gv.w)) != 0u)) g4[base + c] = zero;
+            }
+        }
+        return;
+    }
+    const bool act = lane < row4;
+    int j = mask ? __ffsll((unsigned long long)mask) - 1 : -1;
+    if (j >= 0) mask &= mask - 1;
+    size_t base = 0;
+    int n = 0;
+    bool wg = false;
+    float4 pv = zero, sv = zero, gv = zero;
+    if (j >= 0) {
+        base = (size_t)__shfl(row, j) * row4 + lane;
+        n = __shfl(n_decay, j);
+        wg = __shfl((int)with_grad, j) != 0;
+        if (act) { pv = p4[base]; sv = s4[base]; if (wg) gv = g4[base]; }
+    }
+    while (j >= 0) {
+        const int jn = mask ? __ffsll((unsigned long long)mask) - 1 : -1;
+        if (jn >= 0) mask &= mask - 1;
+        size_t base_n = 0;
+        int n_n = 0;
+        bool wg_n = false;
+        float4 pn = zero, sn = zero, gn = zero;
+        if (jn >= 0) {                                   // the next row's loads leave before this row's arithmetic starts
+            base_n = (size_t)__shfl(row, jn) * row4 + lane;
+            n_n = __shfl(n_decay, jn);
+            wg_n = __shfl((int)with_grad, jn) != 0;
+            if (act) { pn = p4[base_n]; sn = s4[base_n]; if (wg_n) gn = g4[base_n]; }
+        }
+        if (act) {
+            const float4 p0 = pv, s0 = sv;
+            decay_replay4(pv, sv, n, lr, wd, eps);
+            if (wg) adagrad4(pv, gv, sv, lr, wd, eps);
+            if (bits_differ(pv, p0)) p4[base] = pv;
+            if (bits_differ(sv, s0)) s4[base] = sv;
+            if (wg && ((__float_as_uint(gv.x) | __float_as_uint(gv.y) | __float_as_uint(gv.z) | __float_as_uint(gv.w)) != 0u)) g4[base] = zero;
+        }
+        j = jn; base = base_n; n = n_n; wg = wg_n; pv = pn; sv = sn; gv = gn;
+    }
+}
+
 // Padded leading dimension (floats) of an LDS tile whose rows hold D16 floats: D16 + 4 = 4 * odd, so
 // (a) ds_read_b128 of 16 different rows at one column lands on 16 different 16-byte slots and
 // (b) ds_read_b32 of rows r and r+4 at 16 consecutive columns lands on disjoint bank halves.

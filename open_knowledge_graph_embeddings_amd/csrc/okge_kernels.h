@@ -168,12 +168,17 @@ struct PoolCall {
     float         *d_weight, *d_bias, *dW;  // backward targets
     float         *partial;                 // [ceil(n / 32)][2][d] scratch of this call
     uint8_t       *touched;                 // backward: [vocab] bytes, touched[token] = touched_stamp for every row of dW written (or nullptr)
+    float         *sumW;                    // catch-up (okge_pool_catch_up_calls): Adagrad accumulator of W and
+    int32_t       *steps;                   //   [vocab] optimizer steps each row of W has seen
     int64_t        ld;
     int32_t        d, L, first_id, n, pool, n_ids, vocab, touched_stamp;
     float          eps, momentum;
 };
 size_t pool_workspace_bytes(int n, int d);
 hipError_t launch_pool_encode_calls(const PoolCall *calls, int n_calls, int training, int *id_err, hipStream_t st);
+// rows of W the calls' tokens name: their pending decay-only Adagrad steps (okge_adagrad_lazy), before the forward reads them
+hipError_t launch_pool_catch_up(const PoolCall *calls, int n_calls, const int32_t *counters, float lr, float wd, float eps, int *id_err,
+                                hipStream_t st);
 // state == nullptr: the token-table gradient is scattered with float atomics; otherwise (pool sum / mean, slot sizes that are
 // a multiple of 4): store-and-sum through a device-built inverted index, bit-reproducible (okge_pool.hip, "scatter plan")
 size_t pool_scatter_state_bytes(const PoolCall *calls, int n_calls);
@@ -185,6 +190,11 @@ hipError_t launch_pool_backward_calls(const PoolCall *calls, int n_calls, int *i
 constexpr int ADAGRAD_MAX_SEGS = 4;
 struct AdagradSegM { float *p, *g, *s; int64_t n; const uint8_t *touched; int32_t row_len, stamp, zero_grad, rows; };   // rows: 0 all, 1 unstamped only, 2 stamped only
 hipError_t launch_adagrad_multi(const AdagradSegM *segs, int n_segs, float lr, float wd, float eps, hipStream_t st);
+// deferred weight-decay-only updates (okge_adagrad_lazy; okge_misc.hip): steps == nullptr: a plain dense tensor of rows * row_len floats
+constexpr int LAZY_STEP = 0, LAZY_FLUSH = 1;
+struct LazySeg { float *p, *g, *s; int32_t *steps; uint8_t *touched; int64_t rows; int32_t row_len, stamp; };
+hipError_t launch_adagrad_lazy(const LazySeg *segs, int n_segs, int32_t *counters, int window, int mode, float lr, float wd,
+                               float eps, hipStream_t st);
 hipError_t launch_dc_reduce(const float *slab, int nsplit, int rows_pad, int D16, int N, int d, const int32_t *cand_ids,
                             int cand_first, int exclusive, int grads_zero, float *dE, int64_t table_rows, int *id_err,
                             hipStream_t st);

@@ -350,24 +350,8 @@ __device__ __forceinline__ void atomic_add4(float *p, float4 v)
 // NB: slab loads kept in flight per lane (8 for the single-device step's 32 split-K slabs; 1 for the sharded step, whose dQ
 // arrives already reduced: 89 instead of 149 registers = 5 instead of 3 waves per SIMD, which is what bounds a launch of
 // 4096 one-row workgroups -- 2.7 rounds of a ~7 us dependent-load chain at 3 waves)
-__device__ __forceinline__ bool bits_differ(const float4 &a, const float4 &b)
-{
-    return ((__float_as_uint(a.x) ^ __float_as_uint(b.x)) | (__float_as_uint(a.y) ^ __float_as_uint(b.y)) |
-            (__float_as_uint(a.z) ^ __float_as_uint(b.z)) | (__float_as_uint(a.w) ^ __float_as_uint(b.w))) != 0u;
-}
-
 // ---- okge_train_step: Adagrad inside the step's last launches (AdagradFuse, okge_kernels.h) -------------------------------
-__device__ __forceinline__ void adagrad4(float4 &pv, const float4 &gv, float4 &sv, float lr, float wd, float eps)
-{
-    float *pp = &pv.x, *ss = &sv.x;
-    const float *gg = &gv.x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {                        // the arithmetic of adagrad_sweep, element for element
-        const float gj = fmaf(wd, pp[j], gg[j]);
-        ss[j] = fmaf(gj, gj, ss[j]);
-        pp[j] = pp[j] - lr * (gj / (sqrtf(ss[j]) + eps));
-    }
-}
+// (bits_differ, adagrad4: okge_device.h)
 
 // entity rows without a prefix flag: their gradient row is final (the tile kernel stored it, no prefix of the batch names them)
 __device__ __forceinline__ void fused_entity_sweep(const AdagradFuse &af, int wg, int n_wgs)
@@ -889,6 +873,71 @@ __global__ __launch_bounds__(256) void adagrad_multi_kernel(const AdagradSegsDev
         }
 }
 
+// ---- okge_adagrad_lazy: the weight-decay-only updates of rows no batch names, deferred ------------------------------------
+// The reference's Adagrad reaches every row of a table every step (weight_decay 1e-10 makes every gradient row non-zero,
+// utils/optim.py:139-160): at BASELINE configs[4] 85 % of the token rows are read, moved by their own decay term and written
+// back per step -- 1 GB of HBM traffic, 175 us of a 0.78 ms step.  Such a row's update depends on (p, sum) of that row alone,
+// so it can be applied LATER, all pending steps at once in registers, as long as it has happened before anything reads the row:
+//   row_steps[r]   number of optimizer steps row r has seen; counters[0] = T, the steps taken
+//   STEP           rows the backward stamped: their T - row_steps[r] pending decay steps, then this step with the gradient;
+//                  rows with r % window == T % window: their T + 1 - row_steps[r] pending decay steps; T += 1 (last workgroup)
+//   catch-up       (okge_pool.hip, before the pooling forward) brings the rows the batch's tokens name to T
+//   FLUSH          every row to T (before anything else reads the tables: evaluation, checkpoints, the host)
+// Per step the sweep touches the stamped rows and 1 / window of the others: the traffic falls by ~window, the arithmetic
+// (correctly rounded sqrt and division per element and pending step) stays and becomes the bound.  Same operations in the
+// same order per element as the eager sweep: the tables are bit-identical after a FLUSH (tests/test_token_pooled.py).
+struct LazySegsDev { LazySeg s[ADAGRAD_MAX_SEGS]; int n; int64_t batch0[ADAGRAD_MAX_SEGS + 1]; };
+
+constexpr int LAZY_BATCH = 16;         // rows per wave and turn: many short waves (8 per SIMD) hide the rows' load latency
+
+__global__ __launch_bounds__(256, 8) void adagrad_lazy_kernel(const LazySegsDev segs, int32_t *counters, int window, int mode, float lr,
+                                                           float wd, float eps)
+{
+    const int T = counters[0], target = mode == LAZY_STEP ? T + 1 : T;
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    const int phase = T % window;
+    // tensors with a row_steps array: batches of LAZY_BATCH rows, one per wave at a time; lane = row while the batch's bytes
+    // and counters are read, lane = column quad while a row is updated
+    for (int64_t b = gw; b < segs.batch0[segs.n]; b += nw) {
+        int k = 0;
+        while (b >= segs.batch0[k + 1]) ++k;
+        const LazySeg &sg = segs.s[k];
+        const int64_t r = (b - segs.batch0[k]) * LAZY_BATCH + (lane & (LAZY_BATCH - 1));
+        const bool in = lane < LAZY_BATCH && r < sg.rows;
+        const int up = in ? sg.steps[r] : target;
+        const bool stamped = mode == LAZY_STEP && in && sg.touched && sg.touched[r] == (uint8_t)sg.stamp;
+        const bool due = in && (mode == LAZY_FLUSH || (int)((uint32_t)r % (uint32_t)window) == phase);      // (rows < 2^31: okge_api.hip)
+        const bool need = stamped || (due && up < target);
+        lazy_rows(__ballot(need), r, max(0, (stamped ? T : target) - up), stamped, sg.p, sg.s, sg.g, sg.row_len, lane, lr, wd, eps);
+        if (need) {
+            sg.steps[r] = target;
+            if (stamped) sg.touched[r] = 0;              // the map is clean again: a stamp never has to move on
+        }
+    }
+    // plain dense tensors (batch-norm parameters): every element every step
+    if (mode == LAZY_STEP) {
+        const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+        for (int k = 0; k < segs.n; ++k) {
+            const LazySeg &sg = segs.s[k];
+            if (sg.steps) continue;
+            const int64_t n = sg.rows * sg.row_len;
+            for (int64_t i = first; i < n; i += stride) {
+                const float gj = fmaf(wd, sg.p[i], sg.g[i]);
+                sg.s[i] = fmaf(gj, gj, sg.s[i]);
+                sg.p[i] = sg.p[i] - lr * (gj / (sqrtf(sg.s[i]) + eps));
+                sg.g[i] = 0.f;
+            }
+        }
+        // every workgroup has read T by the time the last one arrives here
+        __shared__ int last;
+        __syncthreads();
+        if (threadIdx.x == 0) last = atomicAdd(&counters[1], 1) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (last && threadIdx.x == 0) { counters[1] = 0; counters[0] = T + 1; }
+    }
+}
+
 constexpr int RANK_GROUPS = 8;
 
 // Count, for NG answer groups of one row at once, how many (filter-corrected) scores are greater than / equal to
@@ -1406,6 +1455,24 @@ hipError_t launch_adagrad_multi(const AdagradSegM *segs, int n_segs, float lr, f
     }
     const int blocks = (int)std::min((int64_t)16384, (n4 + 255) / 256);
     hipLaunchKernelGGL(adagrad_multi_kernel, dim3(blocks), dim3(256), 0, st, a, lr, wd, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_adagrad_lazy(const LazySeg *segs, int n_segs, int32_t *counters, int window, int mode, float lr, float wd,
+                               float eps, hipStream_t st)
+{
+    if (n_segs <= 0) return hipSuccess;
+    if (n_segs > ADAGRAD_MAX_SEGS || window < 1 || !counters) return hipErrorInvalidValue;
+    LazySegsDev a;
+    std::memset(&a, 0, sizeof(a));
+    a.n = n_segs;
+    for (int k = 0; k < n_segs; ++k) {
+        a.s[k] = segs[k];
+        a.batch0[k + 1] = a.batch0[k] + (segs[k].steps ? (segs[k].rows + LAZY_BATCH - 1) / LAZY_BATCH : 0);
+    }
+    // (8 waves per SIMD resident; a wave takes batch after batch)
+    const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>((a.batch0[n_segs] + 3) / 4, 256 * 8));
+    hipLaunchKernelGGL(adagrad_lazy_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a, counters, window, mode, lr, wd, eps);
     return hipGetLastError();
 }
 

@@ -364,6 +364,48 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const PoolBatch pb, int
     }
 }
 
+// Catch-up of the deferred decay-only Adagrad steps (okge_adagrad_lazy, okge_misc.hip): every token row this batch names is
+// brought to the current step BEFORE the pooling forward reads it.  Lane = (row, position) pair; a pair whose token row lags
+// claims it with an integer atomicMax on the row's step counter (the first claim wins: one owner per row however many pairs
+// name it), then the wave replays its claimed rows, lane = column quad (lazy_rows, okge_device.h).  Rows named every step (the
+// frequent tokens) never lag.  Token 0 -- the padding id of every short sequence (model.py:579-586): half the pairs at
+// configs[4], and a row the backward never stamps -- is claimed by ONE lane per call instead (tens of thousands of atomics on
+// one address took 0.4 ms).
+constexpr int CATCH_ROWS = 8, CATCH_PAIRS = 16;
+
+__global__ __launch_bounds__(256, 8) void pool_catch_up_kernel(const PoolBatch pb, const int32_t *__restrict__ counters, float lr, float wd,
+                                                            float eps)
+{
+    int lb;
+    const PoolCall &q = pb.c[locate_call(pb, blockIdx.x, lb)];
+    if (!q.steps) return;
+    const int T = counters[0];
+    const int L = q.L, r0 = lb * CATCH_ROWS, nr = min(q.n, r0 + CATCH_ROWS) - r0, lane = threadIdx.x & 63;
+    float *W = const_cast<float *>(q.W);
+    // CATCH_PAIRS pairs per wave and turn: many short waves, like adagrad_lazy_kernel
+    for (int i0 = (threadIdx.x >> 6) * CATCH_PAIRS; i0 < nr * L; i0 += 4 * CATCH_PAIRS) {
+        const int i = i0 + lane;
+        int tok = -1, from = T;
+        if (lane < CATCH_PAIRS && i < nr * L) tok = q.tokens[(size_t)row_id(q.ids, q.first_id, r0 + i / L, q.n_ids, nullptr) * L + i % L];
+        if (tok == 0) tok = -1;                                  // (below: the call's first workgroup looks after row 0)
+        bool claim = false;
+        if ((unsigned)tok < (unsigned)q.vocab && q.steps[tok] < T) {
+            from = atomicMax(&q.steps[tok], T);
+            claim = from < T;
+        }
+        lazy_rows(__ballot(claim), tok, T - from, false, W, q.sumW, q.sumW, q.d, lane, lr, wd, eps);
+    }
+    if (lb == 0 && threadIdx.x < 64) {                           // row 0, whether or not the first pair names it
+        int from = T;
+        bool claim = false;
+        if (lane == 0 && q.vocab > 0 && q.steps[0] < T) {
+            from = atomicMax(&q.steps[0], T);
+            claim = from < T;
+        }
+        lazy_rows(__ballot(claim), 0, T - from, false, W, q.sumW, q.sumW, q.d, lane, lr, wd, eps);
+    }
+}
+
 // backward partials: partial[b][0][k] = sum_i dy,  partial[b][1][k] = sum_i dy * xhat      (xhat = (x - mean) * rstd)
 // Thread = (column quad, group of 8 rows), 16-byte loads, the four groups added through LDS in a fixed order (a thread per
 // column walked its 32 rows one 4-byte load after the other: 15 us for 33 MB at configs[4]).  Workgroups behind the
@@ -1077,6 +1119,16 @@ hipError_t launch_pool_encode_calls(const PoolCall *calls, int n_calls, int trai
     }
     const PoolBatch pa = make_batch(bn, nb, id_err, [](const PoolCall &q) { return (q.n + BN_ROWS - 1) / BN_ROWS; });
     hipLaunchKernelGGL(bn_apply_kernel, dim3(pa.cum[nb] + (training ? 1 : 0)), dim3(256), 0, st, pa, training);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_catch_up(const PoolCall *calls, int n_calls, const int32_t *counters, float lr, float wd, float eps, int *id_err,
+                                hipStream_t st)
+{
+    if (n_calls <= 0) return hipSuccess;
+    if (n_calls > POOL_MAX_CALLS || !counters) return hipErrorInvalidValue;
+    const PoolBatch pb = make_batch(calls, n_calls, id_err, [](const PoolCall &q) { return (q.n + CATCH_ROWS - 1) / CATCH_ROWS; });
+    hipLaunchKernelGGL(pool_catch_up_kernel, dim3(pb.cum[n_calls]), dim3(256), 0, st, pb, counters, lr, wd, eps);
     return hipGetLastError();
 }
 

@@ -471,6 +471,28 @@ class HotPath:
         N.check(self.lib.okge_adagrad_multi(arr, len(tensors), float(lr), float(weight_decay), float(eps), self._stream()),
                 "okge_adagrad_multi")
 
+    @staticmethod
+    def lazy_tensors(tensors):
+        """(p, g, state_sum[, row_steps, touched_map, stamp]) tuples -> the okge_lazy_tensor array of okge_adagrad_lazy"""
+        arr = (N.LazyTensor * len(tensors))()
+        for a, t in zip(arr, tensors):
+            p, g, s = t[:3]
+            a.p, a.g, a.state_sum = p.data_ptr(), g.data_ptr(), s.data_ptr()
+            if len(t) > 3 and t[3] is not None:
+                a.rows, a.row_len, a.row_steps = p.shape[0], p.shape[1], t[3].data_ptr()
+                if len(t) > 4 and t[4] is not None:
+                    a.row_touched, a.touched_stamp = t[4].data_ptr(), int(t[5])
+            else:
+                a.rows, a.row_len = 1, p.numel()
+        return arr
+
+    def adagrad_lazy(self, tensors, counters, window, flush, lr, weight_decay=1e-10, eps=1e-8):
+        """okge_adagrad_lazy: the update with the weight-decay-only steps of rows no batch names deferred (flush=False: one
+        optimizer step; flush=True: every row brought to the current step).  counters: int32[2] on the device."""
+        arr = self.lazy_tensors(tensors)
+        N.check(self.lib.okge_adagrad_lazy(arr, len(tensors), counters.data_ptr(), int(window), 1 if flush else 0, float(lr),
+                                           float(weight_decay), float(eps), self._stream()), "okge_adagrad_lazy")
+
     def clip_grad_norm_(self, g0, g1, max_norm, norm_out=None):
         """torch.nn.utils.clip_grad_norm_ over two dense gradient tensors, in place (trainer.py:236-240)"""
         if getattr(self, "_clip_ws", None) is None:

@@ -492,3 +492,9 @@ class ReplicaStep:
         self.exchange(batch, loss, ready)
         self.inner.optimizer_step()
         return loss
+
+    def flush(self):
+        """settle what the inner step defers (TokenPooledTrainStep.decay_window): call before reading its tables"""
+        f = getattr(self.inner, "flush", None)
+        if f is not None:
+            f()

@@ -57,6 +57,8 @@ class TokenSlot:
         # skips the gradient rows that do not carry the current stamp (okge.h); the stamp moves on after every update
         self.touched = torch.zeros(W.shape[0], dtype=torch.uint8, device=dev) if d % 4 == 0 else None
         self.stamp = 1
+        # optimizer steps every row has seen (TokenPooledTrainStep, decay_window > 1: deferred weight-decay-only updates)
+        self.row_steps = torch.zeros(W.shape[0], dtype=torch.int32, device=dev) if d % 4 == 0 else None
 
     def next_stamp(self):
         self.stamp = self.stamp % 255 + 1
@@ -176,6 +178,17 @@ class PoolEngine:
                                                 self._ws_bytes, self._stream()), "okge_pool_encode_calls")
         del keep
 
+    def catch_up_calls(self, calls, lazy, counters, lr, weight_decay, eps):
+        """okge_pool_catch_up_calls: the token rows the calls name take their pending decay-only Adagrad steps (before the
+        forward reads them).  calls: as encode_calls; lazy: hotpath.HotPath.lazy_tensors(...)"""
+        calls = [c for c in calls if c[3] > 0]
+        if not calls:
+            return
+        arr, keep = self._calls(calls, False)
+        N.check(self.lib.okge_pool_catch_up_calls(arr, len(calls), lazy, len(lazy), counters.data_ptr(), float(lr), float(weight_decay),
+                                                  float(eps), self._stream()), "okge_pool_catch_up_calls")
+        del keep
+
     def backward_calls(self, calls):
         calls = [c for c in calls if c[3] > 0]
         if not calls:
@@ -197,8 +210,23 @@ class TokenPooledTrainStep:
     (Trainer.compute_one_batch, trainer.py:181-257, over model.py:762-796)."""
 
     def __init__(self, entity: TokenSlot, relation: TokenSlot, scorer, loss="bce", lr=0.1, weight_decay=1e-10, eps=1e-8,
-                 label_smoothing=0.0, dropout=0.0, seed=0, engine=None, overlap_sweep=None):
+                 label_smoothing=0.0, dropout=0.0, seed=0, engine=None, overlap_sweep=None, decay_window=None):
         self.entity, self.relation, self.scorer, self.loss = entity, relation, scorer, loss
+        # decay_window (OKGE_LAZY_DECAY, default 8; 1 = every row every step): the reference's Adagrad moves EVERY token row in
+        # every step by its weight-decay term (utils/optim.py:139-160) -- 1 GB of read-modify-write at configs[4], 175 us of a
+        # 0.78 ms step, for rows nothing reads.  With a window W > 1 a row no batch names takes its pending decay-only steps
+        # later, all at once in registers (okge_adagrad_lazy, okge.h): when a batch names it (catch-up before the forward),
+        # when its turn in the rotating 1/W sweep comes, or at flush().  Same operations, same order: after flush() the tables
+        # are bit-identical to W = 1 (test_lazy_decay_is_bit_equal_to_the_eager_sweep).  CONTRACT: between steps, rows no
+        # batch named may lag by up to W - 1 decay-only steps; everything in this package that reads the tables (evaluation,
+        # state_tensors / checkpoints, the module's encode methods and state_dict) calls flush() first -- do the same before
+        # reading .W / .sumW directly.
+        if decay_window is None:
+            decay_window = int(os.environ.get("OKGE_LAZY_DECAY", "8"))
+        lazy_ok = all(getattr(sl, "row_steps", None) is not None and getattr(sl, "touched", None) is not None for sl in (entity, relation))
+        self.decay_window = max(1, int(decay_window)) if lazy_ok else 1
+        self._counters = torch.zeros(2, dtype=torch.int32, device=entity.W.device)      # [optimizer steps taken, scratch]
+        self._pending = None              # (lr, weight_decay, eps) of the deferred steps; None: every row is current
         # overlap_sweep (OKGE_OVERLAP_SWEEP=1; an experiment, OFF by default): the Adagrad update of the token rows NO token of the
         # batch names (85 % of them at configs[4]; the reference's weight decay reaches every row: 0.9 GB of read-modify-write per
         # step) on a side stream BESIDE the step's matrix kernels -- the pooling forward stamps the rows it reads, so the others are
@@ -223,12 +251,35 @@ class TokenPooledTrainStep:
         self._rows = 0
 
     def state_tensors(self):
+        self.flush()
         out = []
         for sl in (self.entity, self.relation):
             out += [sl.W, sl.dW, sl.sumW]
             if sl.bn is not None:
                 out += [sl.bn, sl.d_bn, sl.sum_bn, sl.running_mean, sl.running_var]
+        if self.decay_window > 1:         # (a caller that restores a snapshot restores the step counters with it)
+            out += [self.entity.row_steps, self.relation.row_steps, self._counters]
         return out
+
+    # -- deferred weight-decay-only updates (decay_window > 1) ---------------------------------------------------------
+    def _hparams(self):
+        return (float(self.lr), float(self.weight_decay), float(self.eps))
+
+    def _lazy_tables(self):
+        return [(sl.W, sl.dW, sl.sumW, sl.row_steps, sl.touched, sl.stamp) for sl in (self.entity, self.relation)]
+
+    def flush(self):
+        """every token row takes the decay-only steps it still owes: afterwards the tables are those of the eager sweep"""
+        if self._pending is None:
+            return
+        lr, wd, eps = self._pending
+        self.engine.adagrad_lazy(self._lazy_tables(), self._counters, self.decay_window, True, lr, wd, eps)
+        self._pending = None
+
+    def _settle_hparams(self):
+        """pending steps were taken with the lr / weight decay / eps of their time: flush before these change"""
+        if self._pending is not None and self._pending != self._hparams():
+            self.flush()
 
     # -- sharded.ReplicaStep protocol: gradients / running statistics as views into one flat exchange buffer ---------
     def grad_tensors(self):
@@ -309,13 +360,19 @@ class TokenPooledTrainStep:
         # statistics updated in this order)
         # (only inside step(): a caller that runs forward_backward alone -- the autograd bridge, ReplicaStep, whose other replicas'
         #  rows receive gradients in the exchange -- gets no early update)
-        overlap = (self.overlap_sweep and getattr(self, "_in_step", False) and ent.touched is not None and rel.touched is not None
-                   and not torch.cuda.is_current_stream_capturing())
+        enc_calls = [(c_[0], c_[1], c_[2], c_[3], c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]) for c_ in calls]
+        if self.decay_window > 1:
+            # the token rows this batch names take the decay-only steps they owe before the forward reads them (always
+            # launched: a captured graph must hold it; with nothing pending it reads the batch's step counters and ends)
+            self._settle_hparams()
+            lr, wd, eps = self._hparams()
+            pe.catch_up_calls(enc_calls, self.engine.lazy_tensors(self._lazy_tables()), self._counters, lr, wd, eps)
+        overlap = (self.overlap_sweep and self.decay_window == 1 and getattr(self, "_in_step", False) and ent.touched is not None
+                   and rel.touched is not None and not torch.cuda.is_current_stream_capturing())
         if self._side_done is not None:            # the previous step's side sweep wrote rows this forward may read
             torch.cuda.current_stream(dev).wait_event(self._side_done)
             self._side_done = None
-        pe.encode_calls([(c_[0], c_[1], c_[2], c_[3], c_[4], c_[5] if c_[0].bn is not None else c_[4], c_[7]) for c_ in calls], True,
-                        stamp=overlap)
+        pe.encode_calls(enc_calls, True, stamp=overlap)
         self._early_swept = False
         if overlap:
             if self._side is None:
@@ -359,6 +416,16 @@ class TokenPooledTrainStep:
 
     def optimizer_step(self):
         eng, e, r = self.engine, self.entity, self.relation
+        if self.decay_window > 1:
+            # stamped rows: what they owe + this step with their gradient; one row in decay_window of the others: what they
+            # owe + this step; batch-norm parameters: dense; the device step counter moves on (okge_adagrad_lazy)
+            self._settle_hparams()
+            lr, wd, eps = self._hparams()
+            tensors = self._lazy_tables() + [(sl.bn, sl.d_bn, sl.sum_bn) for sl in (e, r) if sl.bn is not None]
+            eng.adagrad_lazy(tensors, self._counters, self.decay_window, False, lr, wd, eps)
+            self._pending = (lr, wd, eps)
+            self._after_update()
+            return
         # one launch: token tables (gradient rows the backward did not stamp are neither read nor cleared) + batch-norm parameters
         # (after an early sweep of the unstamped rows -- forward_backward, overlap_sweep -- only the stamped rows are left)
         rows = 2 if getattr(self, "_early_swept", False) else 0
@@ -366,7 +433,10 @@ class TokenPooledTrainStep:
         tensors += [(sl.bn, sl.d_bn, sl.sum_bn) for sl in (e, r) if sl.bn is not None]
         self._early_swept = False
         eng.adagrad_multi(tensors, self.lr, self.weight_decay, self.eps)
-        for sl in (e, r):
+        self._after_update()
+
+    def _after_update(self):
+        for sl in (self.entity, self.relation):
             sl.next_stamp()
         for sl, bn in getattr(self, "module_batchnorms", ()):          # keep an attached nn.Module's parameters current
             bn.weight.data.copy_(sl.bn_weight)
@@ -381,6 +451,10 @@ class TokenPooledTrainStep:
 # ------------------------------------------------------------------------------------------------------------------
 # API-compatible model classes (inference protocol; training goes through TokenPooledTrainStep)
 # ------------------------------------------------------------------------------------------------------------------
+def _flush_before_state_dict(module, prefix, keep_vars):
+    module.flush_steps()
+
+
 class UnigramPoolingRelationEmbedder(RelationEmbedder):
     """openkge/model.py:561-796.  Implemented: pool sum|mean|max, normalize None|'batchnorm', dropout; not implemented
     (raise): normalize='norm', activation, project_relation, sparse gradients.  Training: TokenPooledTrainStep (fused, own
@@ -415,6 +489,21 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
         self.entity_embedding_from_tokens = self.relations_embedding_from_tokens = None
         self.dropout_seed, self.dropout_step = seed, 0
         self._pool_engine = self._engine = None
+        # training drivers that update this module's parameters in place (train_step()): token rows no batch named may owe
+        # decay-only Adagrad steps (TokenPooledTrainStep.decay_window) -- every reader below settles them first
+        self._steps = []
+        self.register_state_dict_pre_hook(_flush_before_state_dict)
+
+    def __getstate__(self):                              # (weak references do not pickle; a copy starts without drivers)
+        state = self.__dict__.copy()
+        state["_steps"] = []
+        return state
+
+    def flush_steps(self):
+        for ref in self._steps:
+            st = ref()
+            if st is not None:
+                st.flush()
 
     # -- plumbing ----------------------------------------------------------------------------------------------
     def engine(self):
@@ -436,6 +525,7 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
     def _encode(self, ids, relation, stream):
         """pool -> batch-norm (batch statistics in training mode, running statistics otherwise) -> dropout -> (n,1,d)"""
         eng = self.engine()
+        self.flush_steps()
         ids = ids.reshape(-1).to(torch.int32).contiguous()
         n, d = ids.numel(), self.slot_size
         emb, tok, bn = (self.relation_embedding, self.relation_token_ids, self.relation_batchnorm) if relation else \
@@ -539,6 +629,7 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
     def autograd_step(self, loss, label_smoothing):
         """the cached TokenPooledTrainStep behind AddLossModule: shares the module's parameters; its optimizer is NOT used
         (the caller's torch optimizer steps the module parameters)"""
+        self.flush_steps()
         st = getattr(self, "_ag_step", None)
         if st is None or st.loss != loss or st.label_smoothing != label_smoothing or st.entity.W.data_ptr() != self.entity_embedding.weight.data_ptr():
             e, r = self._module_slots()
@@ -600,6 +691,8 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
                                   label_smoothing=label_smoothing, dropout=self.entity_dropout, seed=self.dropout_seed)
         if self.entity_batchnorm is not None:
             st.module_batchnorms = ((slots[0], self.entity_batchnorm), (slots[1], self.relation_batchnorm))
+        import weakref
+        self._steps = [r for r in self._steps if r() is not None] + [weakref.ref(st)]
         return st
 
 

@@ -763,6 +763,8 @@ def test_replica_step_token_pooled_one_rank(okge_lib):
             la = float(plain.step(batch)[0])
             lb = float(rep.step(batch)[0])
             assert abs(la - lb) <= 1e-6 * abs(la)
+        plain.flush()
+        rep.flush()
         torch.cuda.synchronize()
         for a, b_ in ((plain.entity, inner.entity), (plain.relation, inner.relation)):
             np.testing.assert_allclose(a.W.cpu().numpy(), b_.W.cpu().numpy(), rtol=1e-4, atol=1e-5)
@@ -928,6 +930,7 @@ def _nccl_replica_worker(rank, world, port, outdir, nsteps):
         rep.step(PrefixBatch(po_rel=t(p["po_rel"]), po_obj=t(p["po_obj"]), sp_subj=t(p["sp_subj"]), sp_rel=t(p["sp_rel"]),
                              pos_row=t(p["rows"]), pos_col=t(p["cols"]), cand_ids=t(p["cand"])))
         sent.append(rep.last_exchanged_elements)
+    rep.flush()
     torch.cuda.synchronize()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), We=e.W.cpu().numpy(), Wr=r.W.cpu().numpy(), bn=e.bn.cpu().numpy(),
              rm=e.running_mean.cpu().numpy(), sent=np.asarray(sent), dense=e.W.numel() + r.W.numel())

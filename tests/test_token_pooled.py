@@ -120,6 +120,7 @@ def test_token_pooled_training_trajectory_vs_oracle(okge_lib):
             ko.adagrad_step(p_, g_, s_, 0.1)
     # Adagrad's early steps amplify 1e-12-level gradient differences where |g| is tiny (see adagrad_tol in
     # tests/test_oracle_golden.py); the per-step losses above are the tight check, the tables a coarse one
+    st.flush()                              # rows no batch named owe decay-only steps until then (decay_window)
     close = np.isclose(e.W.cpu().numpy(), We, rtol=2e-3, atol=2e-4)
     assert close.mean() > 0.95 and np.abs(e.W.cpu().numpy() - We).max() < 0.3        # at most lr per step
     np.testing.assert_allclose(e.running_mean.cpu().numpy(), bn_e["running_mean"], rtol=0, atol=0.1)     # follows W
@@ -220,13 +221,13 @@ def _plan_case(rng, d, L, n_ent, vt_e, N, n_po, n_sp, pool="sum", bn=False, hot_
                 bn_e=mk_bn() if bn else None, bn_r=mk_bn() if bn else None)
 
 
-def _plan_step(c, scorer="complex"):
+def _plan_step(c, scorer="complex", **kw):
     from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch, positives_from_dense
     from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
     bn = c["bn_e"] is not None
     e = TokenSlot(dev(c["We"]), dev(c["ent_tok"]), c["pool"], bn, dev(c["bn_e"]["weight"]) if bn else None, dev(c["bn_e"]["bias"]) if bn else None)
     r = TokenSlot(dev(c["Wr"]), dev(c["rel_tok"]), c["pool"], bn, dev(c["bn_r"]["weight"]) if bn else None, dev(c["bn_r"]["bias"]) if bn else None)
-    st = TokenPooledTrainStep(e, r, scorer)
+    st = TokenPooledTrainStep(e, r, scorer, **kw)
     b = PrefixBatch(cand_ids=dev(c["cand"]), po_rel=dev(c["po"][0]), po_obj=dev(c["po"][1]), sp_subj=dev(c["sp"][0]), sp_rel=dev(c["sp"][1]))
     b.pos_row, b.pos_col = positives_from_dense(dev(c["y"]))
     return st, e, r, b
@@ -282,8 +283,8 @@ def test_touched_map_adagrad_is_bit_equal_to_the_dense_sweep(okge_lib):
     the same steps with the map switched off: tables and accumulators bit-equal"""
     rng = np.random.default_rng(11)
     c = _plan_case(rng, d=64, L=5, n_ent=400, vt_e=3000, N=300, n_po=40, n_sp=40, bn=True, mid_tokens=(45,))
-    a = _plan_step(c)
-    b_ = _plan_step(c)
+    a = _plan_step(c, decay_window=1)
+    b_ = _plan_step(c, decay_window=1)
     b_[1].touched = b_[2].touched = None                         # dense sweep: every gradient row is read
     for _ in range(3):
         a[0].step(a[3])
@@ -308,7 +309,7 @@ def test_overlapped_sweep_is_bit_equal_to_the_plain_step(okge_lib):
         bn = c["bn_e"]
         e = TokenSlot(dev(c["We"]), dev(c["ent_tok"]), "sum", True, dev(bn["weight"]), dev(bn["bias"]))
         r = TokenSlot(dev(c["Wr"]), dev(c["rel_tok"]), "sum", True, dev(c["bn_r"]["weight"]), dev(c["bn_r"]["bias"]))
-        return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=0.1, seed=3, overlap_sweep=overlap), e, r
+        return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=0.1, seed=3, overlap_sweep=overlap, decay_window=1), e, r
     a, b_ = make(True), make(False)
     assert a[0].overlap_sweep and not b_[0].overlap_sweep
     r2 = np.random.default_rng(5)
@@ -330,3 +331,156 @@ def test_overlapped_sweep_is_bit_equal_to_the_plain_step(okge_lib):
     for x, y_ in ((a[1], b_[1]), (a[2], b_[2])):
         assert torch.equal(x.W, y_.W) and torch.equal(x.sumW, y_.sumW) and torch.equal(x.bn, y_.bn) and torch.equal(x.sum_bn, y_.sum_bn)
         assert float(x.dW.abs().max()) == 0.0
+
+
+def _lazy_problem(seed=31):
+    rng = np.random.default_rng(seed)
+    return _plan_case(rng, d=64, L=6, n_ent=2000, vt_e=5000, N=900, n_po=96, n_sp=96, bn=True, mid_tokens=(45,))
+
+
+def _lazy_make(c, window, **kw):
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    e = TokenSlot(dev(c["We"]), dev(c["ent_tok"]), "sum", True, dev(c["bn_e"]["weight"]), dev(c["bn_e"]["bias"]))
+    r = TokenSlot(dev(c["Wr"]), dev(c["rel_tok"]), "sum", True, dev(c["bn_r"]["weight"]), dev(c["bn_r"]["bias"]))
+    return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=0.1, seed=3, decay_window=window, **kw), e, r
+
+
+def _lazy_batch(r2, n_ent=2000, n_rel=40, N=900, B=192, lo=2):
+    """a batch over entity ids [lo, n_ent): different token rows named step after step"""
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch, positives_from_dense
+    y = np.zeros((B, N), np.float32)
+    y[np.arange(B), r2.integers(0, N, B)] = 1
+    b = PrefixBatch(cand_ids=dev(r2.integers(lo, n_ent, N).astype(np.int32)),
+                    po_rel=dev(r2.integers(2, n_rel, B // 2).astype(np.int32)), po_obj=dev(r2.integers(lo, n_ent, B // 2).astype(np.int32)),
+                    sp_subj=dev(r2.integers(lo, n_ent, B // 2).astype(np.int32)), sp_rel=dev(r2.integers(2, n_rel, B // 2).astype(np.int32)))
+    b.pos_row, b.pos_col = positives_from_dense(dev(y))
+    return b
+
+
+def _same_tables(a, b_):
+    for x, y_ in ((a[1], b_[1]), (a[2], b_[2])):
+        assert torch.equal(x.W, y_.W) and torch.equal(x.sumW, y_.sumW), "token table / accumulator differ"
+        assert torch.equal(x.bn, y_.bn) and torch.equal(x.sum_bn, y_.sum_bn)
+        assert float(x.dW.abs().max()) == 0.0 and float(y_.dW.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("window", [2, 3, 8, 64])
+def test_lazy_decay_is_bit_equal_to_the_eager_sweep(okge_lib, window):
+    """decay_window > 1 (okge_adagrad_lazy + okge_pool_catch_up_calls: the weight-decay-only Adagrad steps of token rows no
+    batch names are deferred and replayed in registers) against decay_window = 1 (every row every step, the reference's
+    order): every step's loss bit-equal (the forward reads caught-up rows), tables / accumulators / batch-norm parameters
+    bit-equal after flush() -- over 14 steps of DIFFERENT batches whose ids move through the table (rows go cold and come
+    back), with a flush in the middle and a learning-rate change while steps are pending"""
+    c = _lazy_problem()
+    a, b_ = _lazy_make(c, window), _lazy_make(c, 1)
+    assert a[0].decay_window == window and b_[0].decay_window == 1
+    r2 = np.random.default_rng(5)
+    for step in range(14):
+        lo = 2 + (step % 5) * 290                                  # ids [lo, lo + 800): a sliding part of the entities
+        st0 = r2.bit_generator.state
+        losses = []
+        for st, _, _ in (a, b_):
+            r2.bit_generator.state = st0
+            losses.append(float(st.step(_lazy_batch(r2, n_ent=lo + 800, lo=lo))[0]))
+        assert losses[0] == losses[1], (step, losses)
+        if step == 6:
+            a[0].flush()
+            torch.cuda.synchronize()
+            _same_tables(a, b_)
+            assert int(a[1].row_steps.min()) == int(a[1].row_steps.max()) == 7 == int(a[0]._counters[0])
+        if step == 9:
+            a[0].lr = b_[0].lr = 0.05                              # pending steps keep the rate of their time
+    lag = int(a[0]._counters[0]) - a[1].row_steps
+    assert int(lag.max()) <= window and int(lag.min()) >= 0
+    if window <= 8:
+        assert int(lag.max()) > 0, "nothing was deferred: the test does not exercise the replay"
+    a[0].flush()
+    torch.cuda.synchronize()
+    _same_tables(a, b_)
+    assert int(a[1].touched.max()) == 0 and int(a[2].touched.max()) == 0          # the map is clean after every update
+    from open_knowledge_graph_embeddings_amd import _native as N
+    N.check_ids()
+
+
+def test_lazy_decay_with_warm_accumulators_and_state_snapshot(okge_lib):
+    """accumulators that have seen real gradients: the decay term is below half an ulp, a replayed step returns its input
+    bits and the replay loop ends early -- still bit-equal; state_tensors() flushes and carries the step counters, so a
+    snapshot / restore (GraphedTrainStep's warm-up) is exact"""
+    c = _lazy_problem(32)
+    a, b_ = _lazy_make(c, 8), _lazy_make(c, 1)
+    for st, e, r in (a, b_):
+        e.sumW.fill_(1e-4)
+        r.sumW.fill_(1e-4)
+    r2 = np.random.default_rng(6)
+    snap = None
+    for step in range(10):
+        st0 = r2.bit_generator.state
+        for st, _, _ in (a, b_):
+            r2.bit_generator.state = st0
+            st.step(_lazy_batch(r2))
+        if step == 4:
+            snap = [t.clone() for t in a[0].state_tensors()]
+    a[0].flush()
+    torch.cuda.synchronize()
+    _same_tables(a, b_)
+    final = [t.clone() for t in a[0].state_tensors()]
+    for t, s0 in zip(a[0].state_tensors(), snap):                  # back to step 5, the same five batches again
+        t.copy_(s0)
+    a[0].steps = 5
+    r2 = np.random.default_rng(6)
+    for step in range(10):
+        b = _lazy_batch(r2)
+        if step >= 5:
+            a[0].step(b)
+    for t, f in zip(a[0].state_tensors(), final):
+        assert torch.equal(t, f)
+
+
+def test_lazy_decay_under_graph_replay(okge_lib):
+    """the step with deferred decay captured in a HIP graph (device-side step counter, catch-up and lazy update inside the
+    graph): tables bit-equal to the eager sweep launched step by step"""
+    from open_knowledge_graph_embeddings_amd.train_step import GraphedTrainStep
+    c = _lazy_problem(33)
+    a, b_ = _lazy_make(c, 4), _lazy_make(c, 1)
+    r2 = np.random.default_rng(7)
+    batches = [_lazy_batch(r2, n_ent=600 + 400 * i, lo=2 + 300 * i) for i in range(4)]
+    cap = max(b.nnz for b in batches)
+    g = GraphedTrainStep(a[0], batches[0], pos_capacity=cap)
+    for i in range(9):
+        la = float(g.step(batches[i % 4])[0])
+        lb = float(b_[0].step(batches[i % 4])[0])
+        assert la == lb, (i, la, lb)
+    a[0]._pending = a[0]._hparams()                                # (replays do not pass through the Python step)
+    a[0].flush()
+    torch.cuda.synchronize()
+    _same_tables(a, b_)
+
+
+def test_module_readers_flush_the_training_driver(okge_lib):
+    """UnigramPooling*RelationModel.train_step() updates the module's parameters in place with deferred decay: the module's
+    own readers (eval-mode precompute, state_dict) see the tables of the eager sweep"""
+    from open_knowledge_graph_embeddings_amd.dataset import EntityRelationDatasetMeta
+    from open_knowledge_graph_embeddings_amd.token_pooled import UnigramPoolingComplexRelationModel
+    rng = np.random.default_rng(9)
+    n_ent, n_rel, vt, L, d = 300, 20, 900, 4, 32
+    md = EntityRelationDatasetMeta(entities_size=n_ent, relations_size=n_rel, entity_tokens_size=vt, relation_tokens_size=60, max_length=(L, L),
+                                   entity_id_to_tokens_map=[[int(t) for t in rng.integers(1, vt, L)] for _ in range(n_ent)],
+                                   relation_id_to_tokens_map=[[int(t) for t in rng.integers(1, 60, L)] for _ in range(n_rel)])
+    outs = []
+    for window in (8, 1):
+        torch.manual_seed(0)
+        m = UnigramPoolingComplexRelationModel(entity_slot_size=d, relation_slot_size=d, train_data=md, pool="sum", normalize="batchnorm",
+                                               dropout=0.0, init_std=0.3).cuda()
+        st = m.train_step(lr=0.1)
+        st.decay_window = window if st.decay_window > 1 else 1
+        r2 = np.random.default_rng(4)
+        for _ in range(5):
+            st.step(_lazy_batch(r2, n_ent=n_ent, n_rel=n_rel, N=64, B=32))
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        m.eval()
+        with torch.no_grad():
+            m.precompute_embeddings_from_tokens()
+        outs.append((sd, m.entity_embedding_from_tokens.clone()))
+    for k in outs[0][0]:
+        assert torch.equal(outs[0][0][k], outs[1][0][k]), k
+    assert torch.equal(outs[0][1], outs[1][1])

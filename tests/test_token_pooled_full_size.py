@@ -165,6 +165,7 @@ def test_token_pooled_step_at_config5_size(okge_lib, problem, reference):
     We, sums = problem["We"].astype(np.float64), np.zeros((V_ENT, D))
     ko.adagrad_step(We, reference["dWe"], sums, 0.1)
     st.optimizer_step()
+    st.flush()
     torch.cuda.synchronize()
     got = st.entity.W.cpu().numpy()
     # first Adagrad step: p -= lr * g / (|g| + 1e-8): rows with |g| ~ 1e-8 amplify fp32 gradient noise; compare where

@@ -89,7 +89,10 @@ def setup_s_olp_tok(dev, rng, t):
     ent = TokenSlot(torch.randn((vt_e, d), device=dev) * 0.1, t(make_token_matrix(rng, n_ent, vt_e, L)), "sum", True)
     rel = TokenSlot(torch.randn((vt_r, d), device=dev) * 0.1, t(make_token_matrix(rng, n_rel, vt_r, L)), "sum", True)
     step = TokenPooledTrainStep(ent, rel, "complex", lr=0.1, dropout=0.1, seed=1)
-    batches = [positives_batch(rng, t, n_ent, n_rel, B, N, 1, cand_ids=t(rng.choice(n_ent - 2, N, replace=False).astype(np.int32) + 2)) for _ in range(2)]
+    # (eight resident batches: a rare token row named by one of them is named again eight steps later -- the deferred decay
+    #  steps it catches up on then are as many as a training run's, where no batch repeats; with two the lag would be one)
+    batches = [positives_batch(rng, t, n_ent, n_rel, B, N, 1, cand_ids=t(rng.choice(n_ent - 2, N, replace=False).astype(np.int32) + 2))
+               for _ in range(int(os.environ.get("OKGE_TOK_BATCHES", "8")))]
     return step, batches, (f"S-OLP-tok: token-pooled ComplEx d={d}, B={B}, batch-shared N={N}, {L} tokens per entity from a {vt_e} / {vt_r} Zipf "
                            f"vocabulary, sum pooling + batch-norm, dropout 0.1, BCE, dense Adagrad over the token tables"), 6.0 * B * N * d, 4.0 * B * N * d
 
@@ -207,6 +210,7 @@ def main():
         # weight-decay-only update of a step that does not touch the row leaves its bits unchanged and the sweep skips the
         # two stores (okge_misc.hip adagrad_sweep).  Two resident batches touch ~15 % of the token rows; in the line above
         # the other rows' accumulators are still ~1e-22 and move every step, as in the first steps of a run.
+        step.flush()
         for sl in (ent, rel):
             sl.sumW.fill_(1e-4)
         run("S-OLP-tok (accumulators of a run in progress)", step, batches, steps=20, warmup=3)
