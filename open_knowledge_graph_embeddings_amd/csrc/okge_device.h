@@ -191,17 +191,99 @@ __device__ __forceinline__ void adagrad4(float4 &pv, const float4 &gv, float4 &s
     }
 }
 
+// ---- decay-only steps on operands known to be ordinary numbers --------------------------------------------------------------
+// The compiler's correctly rounded `sqrtf` and `/` spend a third of their instructions on operands that cannot occur here
+// (denormal / huge / zero / infinite: `v_div_scale` x2 + `v_div_fixup`, the 2^32 scaling and class test around `v_sqrt_f32`), and
+// none of their fix-up arithmetic is packed.  The replay of deferred steps is bound by exactly this arithmetic, so it
+// runs the SAME sequences -- `v_sqrt_f32` + the two neighbour tests; `v_rcp_f32` + the Newton step on the reciprocal + two
+// residual corrections of the quotient -- on two elements at a time (`v_pk_fma_f32`), without the branches for operands outside
+//     sqrt:  2^-96 <= x < inf                    (below: scaled by 2^32 first;  v_cmp_gt 0x0f800000 in the generic code)
+//     a / b: a, b != 0, b and 1/b and a/b normal, exponent(a) - exponent(b) < 96, |a| >= 2^-103      (V_DIV_SCALE_F32 leaves
+//            both operands as they are and VCC = 0; V_DIV_FMAS_F32 is then a plain fma and V_DIV_FIXUP_F32 returns its operand)
+// Inside that range the result is the generic one bit for bit (the same instructions on the same values);
+// tests/test_token_pooled.py::test_fast_decay_arithmetic_is_the_generic_one compares the two over twelve orders of magnitude.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v fma2(f2v a, f2v b, f2v c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ f2v sqrt_rn_ordinary2(f2v x)
+{
+    f2v y, dn, up;
+    y.x = __builtin_amdgcn_sqrtf(x.x);
+    y.y = __builtin_amdgcn_sqrtf(x.y);
+    dn.x = __int_as_float(__float_as_int(y.x) - 1);
+    dn.y = __int_as_float(__float_as_int(y.y) - 1);
+    up.x = __int_as_float(__float_as_int(y.x) + 1);
+    up.y = __int_as_float(__float_as_int(y.y) + 1);
+    const f2v e_dn = fma2(-dn, y, x), e_up = fma2(-up, y, x);
+    f2v r;
+    r.x = 0.f >= e_dn.x ? dn.x : y.x;
+    r.y = 0.f >= e_dn.y ? dn.y : y.y;
+    r.x = 0.f < e_up.x ? up.x : r.x;
+    r.y = 0.f < e_up.y ? up.y : r.y;
+    return r;
+}
+
+__device__ __forceinline__ f2v div_rn_ordinary2(f2v a, f2v b)
+{
+    f2v r0;
+    r0.x = __builtin_amdgcn_rcpf(b.x);
+    r0.y = __builtin_amdgcn_rcpf(b.y);
+    const f2v one = {1.f, 1.f};
+    const f2v r = fma2(fma2(-b, r0, one), r0, r0);
+    f2v q = a * r;
+    q = fma2(fma2(-b, q, a), r, q);
+    q = fma2(fma2(-b, q, a), r, q);
+    return q;
+}
+
+// may `n` decay-only steps from (p, s) take the sequences above?  Bounds with room for n <= 64 steps of drift (|p| moves by at
+// most lr * wd / eps <= 1/16 of itself per step, s grows by g^2 <= 2^20 per step); the parameters' own ranges are checked once
+__device__ __forceinline__ bool decay_params_ordinary(float lr, float wd, float eps)
+{
+    return wd >= 0x1p-40f && wd <= 0x1p-10f && eps >= 0x1p-40f && eps <= 1.f && lr > 0.f && lr <= 16.f && lr * wd <= 0x1p-4f * eps;
+}
+__device__ __forceinline__ bool decay_operands_ordinary(const float4 &pv, const float4 &sv)
+{
+    const float *pp = &pv.x, *ss = &sv.x;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)          // (unsigned compares of the bit patterns: one subtract + one compare per bound pair)
+        ok = ok && (__float_as_uint(fabsf(pp[j])) - 0x26800000u) <= (0x49800000u - 0x26800000u)      // 2^-50 <= |p| <= 2^20
+                && (__float_as_uint(ss[j]) - 0x0f800000u) <= (0x53800000u - 0x0f800000u);              // 2^-96 <= s <= 2^40
+    return ok;
+}
+
+__device__ __forceinline__ void decay_step4_ordinary(float4 &pv, float4 &sv, float lr, float wd, float eps)
+{
+    const f2v wd2 = {wd, wd}, eps2 = {eps, eps}, nlr2 = {-lr, -lr}, zero2 = {0.f, 0.f};
+    f2v p01 = {pv.x, pv.y}, p23 = {pv.z, pv.w}, s01 = {sv.x, sv.y}, s23 = {sv.z, sv.w};
+    const f2v g01 = fma2(wd2, p01, zero2), g23 = fma2(wd2, p23, zero2);
+    s01 = fma2(g01, g01, s01);
+    s23 = fma2(g23, g23, s23);
+    p01 = fma2(nlr2, div_rn_ordinary2(g01, sqrt_rn_ordinary2(s01) + eps2), p01);
+    p23 = fma2(nlr2, div_rn_ordinary2(g23, sqrt_rn_ordinary2(s23) + eps2), p23);
+    pv = make_float4(p01.x, p01.y, p23.x, p23.y);
+    sv = make_float4(s01.x, s01.y, s23.x, s23.y);
+}
+
 // `n` consecutive updates of a row no gradient reached (g = 0: the weight-decay term alone, okge_adagrad_lazy): the same
 // arithmetic as n sweeps, one after the other.  If the first step returns the bits it was given on every active lane of the wave
-// (warm accumulators: wd * p is below half an ulp of both), all later ones do too and are skipped.
+// (warm accumulators: wd * p is below half an ulp of both), all later ones do too and are skipped.  `ordinary` (wave-uniform):
+// every active lane's operands allow the short sequences above.
 __device__ __forceinline__ void decay_replay4(float4 &pv, float4 &sv, int n, float lr, float wd, float eps)
 {
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n <= 0) return;
+    const bool ordinary = n <= 64 && decay_params_ordinary(lr, wd, eps) && !__any(!decay_operands_ordinary(pv, sv));
     const float4 p0 = pv, s0 = sv;
-    adagrad4(pv, zero, sv, lr, wd, eps);
+    if (ordinary) decay_step4_ordinary(pv, sv, lr, wd, eps);
+    else adagrad4(pv, zero, sv, lr, wd, eps);
     if (!__any(bits_differ(pv, p0) || bits_differ(sv, s0))) return;      // (checked once: a row that moves keeps moving)
-    for (int i = 1; i < n; ++i) adagrad4(pv, zero, sv, lr, wd, eps);
+    if (ordinary) {
+        for (int i = 1; i < n; ++i) decay_step4_ordinary(pv, sv, lr, wd, eps);
+    } else {
+        for (int i = 1; i < n; ++i) adagrad4(pv, zero, sv, lr, wd, eps);
+    }
 }
 
 // The rows a wave owes work on, one after the other with the NEXT row's loads in flight while the current one is replayed

@@ -888,10 +888,10 @@ __global__ __launch_bounds__(256) void adagrad_multi_kernel(const AdagradSegsDev
 // same order per element as the eager sweep: the tables are bit-identical after a FLUSH (tests/test_token_pooled.py).
 struct LazySegsDev { LazySeg s[ADAGRAD_MAX_SEGS]; int n; int64_t batch0[ADAGRAD_MAX_SEGS + 1]; };
 
-constexpr int LAZY_BATCH = 16;         // rows per wave and turn: many short waves (8 per SIMD) hide the rows' load latency
+constexpr int LAZY_BATCH = 16;         // rows per wave and turn: many short turns hide the rows' load latency
 
-__global__ __launch_bounds__(256, 8) void adagrad_lazy_kernel(const LazySegsDev segs, int32_t *counters, int window, int mode, float lr,
-                                                           float wd, float eps)
+__device__ __forceinline__ void adagrad_lazy_body(const LazySegsDev &segs, int32_t *counters, int window, int mode, float lr, float wd,
+                                                  float eps)
 {
     const int T = counters[0], target = mode == LAZY_STEP ? T + 1 : T;
     const int lane = threadIdx.x & 63;
@@ -936,6 +936,14 @@ __global__ __launch_bounds__(256, 8) void adagrad_lazy_kernel(const LazySegsDev 
         __syncthreads();
         if (last && threadIdx.x == 0) { counters[1] = 0; counters[0] = T + 1; }
     }
+}
+
+// 93 registers = 5 waves per SIMD.  Budgets of 80 / 64 registers (6 / 8 waves) spill inside the replay loops: 85 / 130 us against
+// 70 us at configs[4] (profiles/round4_ablation.md section 6)
+__global__ __launch_bounds__(256, 5) void adagrad_lazy_kernel(const LazySegsDev segs, int32_t *counters, int window, int mode, float lr,
+                                                           float wd, float eps)
+{
+    adagrad_lazy_body(segs, counters, window, mode, lr, wd, eps);
 }
 
 constexpr int RANK_GROUPS = 8;
@@ -1470,8 +1478,8 @@ hipError_t launch_adagrad_lazy(const LazySeg *segs, int n_segs, int32_t *counter
         a.s[k] = segs[k];
         a.batch0[k + 1] = a.batch0[k] + (segs[k].steps ? (segs[k].rows + LAZY_BATCH - 1) / LAZY_BATCH : 0);
     }
-    // (8 waves per SIMD resident; a wave takes batch after batch)
-    const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>((a.batch0[n_segs] + 3) / 4, 256 * 8));
+    // (every wave resident: 5 per SIMD; a wave takes batch after batch)
+    const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>((a.batch0[n_segs] + 3) / 4, 256 * 5));
     hipLaunchKernelGGL(adagrad_lazy_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a, counters, window, mode, lr, wd, eps);
     return hipGetLastError();
 }

@@ -276,6 +276,11 @@ class TokenPooledTrainStep:
         self.engine.adagrad_lazy(self._lazy_tables(), self._counters, self.decay_window, True, lr, wd, eps)
         self._pending = None
 
+    def mark_pending(self):
+        """a captured graph holding this step was replayed: rows may owe steps again (GraphedTrainStep)"""
+        if self.decay_window > 1:
+            self._pending = self._hparams()
+
     def _settle_hparams(self):
         """pending steps were taken with the lr / weight decay / eps of their time: flush before these change"""
         if self._pending is not None and self._pending != self._hparams():
@@ -633,8 +638,9 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
         st = getattr(self, "_ag_step", None)
         if st is None or st.loss != loss or st.label_smoothing != label_smoothing or st.entity.W.data_ptr() != self.entity_embedding.weight.data_ptr():
             e, r = self._module_slots()
+            # (decay_window = 1: this step's own optimizer never runs -- the caller's torch optimizer moves every row every step)
             st = self._ag_step = TokenPooledTrainStep(e, r, self.scorer_name, loss=loss, label_smoothing=label_smoothing,
-                                                      dropout=self.entity_dropout, seed=self.dropout_seed)
+                                                      dropout=self.entity_dropout, seed=self.dropout_seed, decay_window=1)
         for sl, bn in ((st.entity, self.entity_batchnorm), (st.relation, self.relation_batchnorm)):
             sl.dW = torch.zeros_like(sl.W)                        # fresh gradient buffers: the last ones went to autograd
             if bn is not None:                                     # the module's parameters may have been stepped outside

@@ -243,10 +243,12 @@ class GraphedTrainStep:
     def step(self, batch: H.PrefixBatch):
         """Copies the batch into the captured buffers and replays; returns the device loss (double[1])."""
         self._load(batch)
-        self.graph.replay()
-        return self.loss
+        return self.replay()
 
     def replay(self):
         """Replays on whatever the captured buffers hold (a producer may fill `self.static` directly)."""
         self.graph.replay()
+        mark = getattr(self.inner, "mark_pending", None)      # (token-pooled step: deferred decay steps are owed again)
+        if mark is not None:
+            mark()
         return self.loss

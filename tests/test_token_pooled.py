@@ -450,7 +450,10 @@ def test_lazy_decay_under_graph_replay(okge_lib):
         la = float(g.step(batches[i % 4])[0])
         lb = float(b_[0].step(batches[i % 4])[0])
         assert la == lb, (i, la, lb)
-    a[0]._pending = a[0]._hparams()                                # (replays do not pass through the Python step)
+        if i == 4:                                                 # a reader in the middle of the run: flush, then go on replaying
+            a[0].flush()
+            torch.cuda.synchronize()
+            _same_tables(a, b_)
     a[0].flush()
     torch.cuda.synchronize()
     _same_tables(a, b_)
@@ -484,3 +487,44 @@ def test_module_readers_flush_the_training_driver(okge_lib):
     for k in outs[0][0]:
         assert torch.equal(outs[0][0][k], outs[1][0][k]), k
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("window", [1, 5])
+def test_fast_decay_arithmetic_is_the_generic_one(okge_lib, window):
+    """the replay of deferred decay steps runs packed, branch-free copies of the compiler's correctly rounded sqrt / division
+    where every operand of a row is an ordinary number (okge_device.h, decay_step4_ordinary) and the generic code elsewhere:
+    against the eager sweep (okge_adagrad_multi: generic code throughout) the tables must be bit-equal -- rows of ordinary
+    numbers over twelve orders of magnitude (fast path), rows with zeros, denormal-range accumulators, tiny and huge
+    parameters (generic path), several steps deep"""
+    from open_knowledge_graph_embeddings_amd import hotpath as H
+    eng = H.HotPath(torch.device("cuda:0"))
+    g = torch.Generator(device="cuda").manual_seed(17)
+    rows, d = 6144, 256
+    u = lambda lo, hi: 10.0 ** (lo + (hi - lo) * torch.rand((rows, d), device="cuda", generator=g))      # noqa: E731
+    sign = torch.where(torch.rand((rows, d), device="cuda", generator=g) < 0.5, -1.0, 1.0)
+    p = sign * u(-12, 4)
+    s = u(-27, 10)
+    p[:2048] = (sign * u(-6, 1))[:2048]                      # ordinary rows: every element inside the fast path's range
+    s[:2048] = u(-26, 8)[:2048]
+    s[2048:3072] = 0.0                                        # first steps of a run
+    p[3072:3200, ::7] = 0.0
+    s[3200:3328] = u(-44, -30)[3200:3328]                     # accumulators below 2^-96: the scaled sqrt
+    p[3328:3456] = (sign * u(-30, -14))[3328:3456]
+    p[3456:3584] = (sign * u(5, 12))[3456:3584]
+    for lr, wd, eps in ((0.1, 1e-10, 1e-8), (0.3, 1e-6, 1e-8), (0.05, 1e-10, 1e-10), (0.1, 0.5, 1e-8)):      # (the last: parameters outside)
+        pe, se, ge = p.clone(), s.clone(), torch.zeros_like(p)
+        pl, sl, gl = p.clone(), s.clone(), torch.zeros_like(p)
+        steps_ = torch.zeros(rows, dtype=torch.int32, device="cuda")
+        maps = torch.zeros(rows, dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+        lazy = [(pl, gl, sl, steps_, maps, 1)]
+        for _ in range(7):
+            eng.adagrad_multi([(pe, ge, se)], lr, wd, eps)
+            eng.adagrad_lazy(lazy, cnt, window, False, lr, wd, eps)
+        eng.adagrad_lazy(lazy, cnt, window, True, lr, wd, eps)
+        torch.cuda.synchronize()
+        assert int(cnt[0]) == 7 and int(steps_.min()) == 7
+        same_p, same_s = (pe.view(torch.int32) == pl.view(torch.int32)), (se.view(torch.int32) == sl.view(torch.int32))
+        assert bool(same_p.all()) and bool(same_s.all()), (lr, wd, eps, int((~same_p).sum()), int((~same_s).sum()),
+                                                           (~(same_p & same_s)).any(dim=1).nonzero()[:8].flatten().tolist())
+        assert not torch.equal(pe, p)                         # (the steps did move the table)
