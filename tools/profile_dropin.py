@@ -20,6 +20,8 @@ from open_knowledge_graph_embeddings_amd.trainer import AddLossModule  # noqa: E
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+    if os.environ.get("OKGE_PROFILE_SINGLE_THREAD") == "1":      # backward on the calling thread (no hand-off to the engine's device thread)
+        torch.autograd.set_multithreading_enabled(False)
     dev = torch.device("cuda:0")
     w = synthetic.WORKLOADS["S-FB"]
     host_batches = [synthetic.make_batch(w, seed=1234 + i) for i in range(4)]
