@@ -220,7 +220,7 @@ class TokenPooledTrainStep:
         # are bit-identical to W = 1 (test_lazy_decay_is_bit_equal_to_the_eager_sweep).  CONTRACT: between steps, rows no
         # batch named may lag by up to W - 1 decay-only steps; everything in this package that reads the tables (evaluation,
         # state_tensors / checkpoints, the module's encode methods and state_dict) calls flush() first -- do the same before
-        # reading .W / .sumW directly.
+        # reading .W / .sumW directly, and before DISCARDING a step object whose tables live on (its pending steps go with it).
         if decay_window is None:
             decay_window = int(os.environ.get("OKGE_LAZY_DECAY", "8"))
         lazy_ok = all(getattr(sl, "row_steps", None) is not None and getattr(sl, "touched", None) is not None for sl in (entity, relation))
@@ -685,6 +685,7 @@ class UnigramPoolingRelationEmbedder(RelationEmbedder):
 
     def train_step(self, loss="bce", lr=0.1, weight_decay=1e-10, eps=1e-8, label_smoothing=0.0):
         """The training driver for this model: shares the module's parameters (updated in place)."""
+        self.flush_steps()                 # an earlier driver (another epoch's learning rate, ...) may still owe decay-only steps
         slots = []
         for emb, tok, bn in ((self.entity_embedding, self.entity_token_ids, self.entity_batchnorm),
                              (self.relation_embedding, self.relation_token_ids, self.relation_batchnorm)):
