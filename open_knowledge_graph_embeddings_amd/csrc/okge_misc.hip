@@ -422,6 +422,9 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
                                                                   float *__restrict__ dr_rows, float *__restrict__ de_rows,
                                                                   int distinct, const AdagradFuse af, int B_rows)
 {
+    // blockIdx.y: 128-column chunk of the row (rows longer than 128 floats per half: the chunks were a loop of dependent
+    // round trips inside one workgroup -- 21 us at DistMult d = 512 -- and are workgroups of their own now)
+    if ((int)blockIdx.x >= B_rows && blockIdx.y != 0) return;
     if ((int)blockIdx.x > B_rows) {                      // okge_train_step: workgroups behind the loss reduction sweep the entity table
         fused_entity_sweep(af, (int)blockIdx.x - B_rows - 1, (int)gridDim.x - B_rows - 1);
         return;
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
     };
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (scorer == SC_DISTMULT) {
-        for (int k0 = 0; k0 < d; k0 += 128) {
+        for (int k0 = 128 * blockIdx.y; k0 < d; k0 += 128 * gridDim.y) {
             const int k = k0 + 4 * grp;
             const bool act = k < d, lead = act && sq == 0;
             const float4 ev0 = lead ? *reinterpret_cast<const float4 *>(e + k) : zero4;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(128) void prefix_backward_vec_kernel(const float *_
         return;
     }
     const int h = d >> 1;
-    for (int k0 = 0; k0 < h; k0 += 128) {
+    for (int k0 = 128 * blockIdx.y; k0 < h; k0 += 128 * gridDim.y) {
         const int k = k0 + 4 * grp;
         const bool act = k < h, lead = act && sq == 0;
         float4 e1 = zero4, e2 = zero4, r1 = zero4, r2 = zero4;
@@ -1341,11 +1344,13 @@ hipError_t launch_prefix_backward(const float *E, const float *R, int d, int sco
             af = *fuse;
             sweep_wgs = (int)std::min<int64_t>(16384, (af.n_ent * (d / 4) + 127) / 128);     // one float4 per thread up to 2 M of them
         }
+        const int cols = scorer == SC_DISTMULT ? d : d / 2;
+        const int chunks = fuse ? 1 : std::min(8, (cols + 127) / 128);       // (the fused sweep's workgroups count on a 1-D grid)
         if (nsplit >= 8)
-            hipLaunchKernelGGL(prefix_backward_vec_kernel<8>, dim3(B + 1 + sweep_wgs), dim3(128), 0, st, E, R, d, scorer, p, slab,
+            hipLaunchKernelGGL(prefix_backward_vec_kernel<8>, dim3(B + 1 + sweep_wgs, chunks), dim3(128), 0, st, E, R, d, scorer, p, slab,
                                nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct, af, B);
         else
-            hipLaunchKernelGGL(prefix_backward_vec_kernel<1>, dim3(B + 1 + sweep_wgs), dim3(128), 0, st, E, R, d, scorer, p, slab,
+            hipLaunchKernelGGL(prefix_backward_vec_kernel<1>, dim3(B + 1 + sweep_wgs, chunks), dim3(128), 0, st, E, R, d, scorer, p, slab,
                                nsplit, Bpad, ldq, ent_rows, dE, dR, loss_partials, n_partials, loss_out, dr_rows, de_rows, distinct, af, B);
         if (seg_r || seg_e) {
             const RowSegments rel{rel_order, rel_seg_ptr, seg_r ? n_rel_seg : 0}, ent{ent_order, ent_seg_ptr, seg_e ? n_ent_seg : 0};
