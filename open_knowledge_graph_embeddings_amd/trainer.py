@@ -13,12 +13,15 @@ import torch
 import torch.nn as nn
 from torch.nn import BCEWithLogitsLoss, KLDivLoss
 
+import ctypes
 import os
 
+from . import _native as N
 from . import hotpath as H
 from .metrics import MetricResult
 
 CALLER_THREAD_BACKWARD = os.environ.get("OKGE_BACKWARD_ON_CALLER_THREAD", "1") == "1"
+FAST_CALL = os.environ.get("OKGE_DROPIN_FAST", "1") == "1"      # persistent argument structs for the common training call
 
 
 class _FusedLossFn(torch.autograd.Function):
@@ -127,6 +130,11 @@ class AddLossModule(nn.Module):
         token_model = hasattr(m, "entity_token_ids")
         n_ent, first = m.train_data.entities_size, m.train_data.min_entities_size
         po, sp = inputs
+        if FAST_CALL and not token_model and m.training and torch.is_grad_enabled() and isinstance(labels, tuple) \
+                and not getattr(m, "encode_in_torch", False) and not H.VALIDATE:
+            fast = self._fast_training_call(m, eng, dev, po, sp, labels, use_batch_shared_entities, batch_shared_entities, kind, epoch)
+            if fast is not None:
+                return fast
         batch = H.PrefixBatch()
         if po is not None:
             batch.po_rel, batch.po_obj = _flat(po[0]), _flat(po[1])
@@ -194,6 +202,78 @@ class AddLossModule(nn.Module):
             loss = eng.forward_backward(m.E, m.R, m.scorer_name, batch, None, None, loss=kind, label_smoothing=smoothing,
                                         normalizer=1.0, scores=all_outputs, loss_only=True)
             result = loss.to(torch.float32).reshape(())
+        return result, hook_loss, all_outputs
+
+    def _fast_training_call(self, m, eng, dev, po, sp, labels, use_batch_shared_entities, batch_shared_entities, kind, epoch):
+        """The call the reference Trainer makes thousands of times per epoch -- lookup model in training mode, coordinate labels,
+        int32 id tensors on the device -- with PERSISTENT argument structs: the general path below builds a PrefixBatch, ten
+        DropoutSpec objects and four ctypes structs per call, ~35 us of Python on a step whose kernels take 130 us (the path is
+        host-bound).  Same library call, same flags, same buffers: test_dropin_path.py compares the two
+        bit for bit.  Returns None when an input is not in that form (the general path then converts it)."""
+        prow, pcol = labels
+        ids = []
+        for pair in (po, sp):
+            if pair is not None:
+                ids += [pair[0], pair[1]]
+        for x in (prow, pcol, *ids):
+            if x.dtype != torch.int32 or not x.is_contiguous() or x.device != dev:
+                return None
+        n_ent, first = m.train_data.entities_size, m.train_data.min_entities_size
+        cand = None
+        if batch_shared_entities is None:
+            n = n_ent - first
+        else:
+            cand = batch_shared_entities
+            if cand.dtype != torch.int32 or not cand.is_contiguous() or cand.device != dev:
+                return None
+            n = cand.numel()
+            if n == n_ent - first and not use_batch_shared_entities:
+                cand = None                                         # arange(vocab)[offset:] (dataset.py:872)
+        fd = getattr(self, "_fd", None)
+        if fd is None:
+            t, pb, c, pos = N.Tables(), N.PrefixBatch(), N.Candidates(), N.Positives()
+            pb.drop_po_ent.stream, pb.drop_sp_ent.stream, c.drop.stream = H.STREAM_PO_ENT, H.STREAM_SP_ENT, H.STREAM_CAND
+            pb.drop_po_rel.stream, pb.drop_sp_rel.stream = H.STREAM_PO_REL, H.STREAM_SP_REL
+            fd = self._fd = (t, pb, c, pos, (pb.drop_po_ent, pb.drop_sp_ent, c.drop), (pb.drop_po_rel, pb.drop_sp_rel))
+        t, pb, c, pos, ent_drops, rel_drops = fd
+        E, R = m.E, m.R
+        if E.dtype != torch.float32 or not E.is_contiguous() or not R.is_contiguous() or R.dtype != torch.float32:
+            return None
+        t.E, t.R, t.n_ent, t.n_rel, t.d, t.scorer = E.data_ptr(), R.data_ptr(), E.shape[0], R.shape[0], E.shape[1], N.SCORERS[m.scorer_name]
+        hook_loss = m.after_batch_loss_hook(epoch) if hasattr(m, "after_batch_loss_hook") else None
+        m.dropout_step += 1
+        seed, step = int(m.dropout_seed) & 0xFFFFFFFFFFFFFFFF, int(m.dropout_step) & 0xFFFFFFFF
+        p_ent = float(m.keep_prob_dropout(m.input_dropout, m.dropout))
+        p_rel = float(m.keep_prob_dropout(m.relation_input_dropout, m.relation_dropout))
+        for d_ in ent_drops:
+            d_.p, d_.seed, d_.step = p_ent, seed, step
+        for d_ in rel_drops:
+            d_.p, d_.seed, d_.step = p_rel, seed, step
+        n_po = po[0].numel() if po is not None else 0
+        n_sp = sp[0].numel() if sp is not None else 0
+        pb.po_rel, pb.po_obj = (po[0].data_ptr(), po[1].data_ptr()) if n_po else (None, None)
+        pb.sp_subj, pb.sp_rel = (sp[0].data_ptr(), sp[1].data_ptr()) if n_sp else (None, None)
+        pb.n_po, pb.n_sp = n_po, n_sp
+        c.ids, c.first_id, c.n = (None if cand is None else cand.data_ptr()), int(first), int(n)
+        pos.row, pos.col, pos.nnz = prow.data_ptr(), pcol.data_ptr(), prow.numel()
+        B = n_po + n_sp
+        all_outputs = None
+        if self.training_outputs:
+            all_outputs = torch.empty((B, (n + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :n]
+        clear = cand is None
+        g_e, g_r = (torch.empty_like(E), torch.empty_like(R)) if clear else (torch.zeros_like(E), torch.zeros_like(R))
+        applied = np.float32(1.0) / np.float32(float(B) * float(n))           # (see forward below)
+        loss = torch.empty(1, dtype=torch.float64, device=dev)
+        ws = eng.workspace(B, n, t.d)
+        smoothing = self.bce_label_smoothing if kind == "bce" else 0.0
+        N.check(eng.lib.okge_train_forward_backward(
+            ctypes.byref(t), ctypes.byref(pb), ctypes.byref(c), ctypes.byref(pos), N.LOSSES[kind], float(smoothing), 1.0 / float(applied),
+            N.OKGE_TRAIN_GRADS_ZERO | (N.OKGE_TRAIN_CLEAR_GRADS if clear else 0), loss.data_ptr(), g_e.data_ptr(), g_r.data_ptr(),
+            None if all_outputs is None else all_outputs.data_ptr(), 0 if all_outputs is None else all_outputs.stride(0),
+            ws.data_ptr(), eng._ws_bytes, eng._stream()), "okge_train_forward_backward")
+        if CALLER_THREAD_BACKWARD and torch.autograd.is_multithreading_enabled():
+            torch.autograd.set_multithreading_enabled(False)                   # (see forward below)
+        result = _FusedLossFn.apply(m.entity_embedding.weight, m.relation_embedding.weight, loss, g_e, g_r, eng, float(applied))
         return result, hook_loss, all_outputs
 
     def _variant_result(self, m, batch, kind, smoothing, want_grad, all_outputs, epoch, all_entities, per_direction):

@@ -307,3 +307,47 @@ def test_validate_config_rejects_bad_ids_before_any_kernel(okge_lib, validate_co
     with pytest.raises(N.OkgeError):
         hp.score(E, R, "complex", bad)
     assert N.id_errors() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["all_entities_bce", "id_list_bce_smoothing_outputs", "all_entities_kl"])
+def test_fast_training_call_is_the_general_path(okge_lib, monkeypatch, case):
+    """AddLossModule's persistent-descriptor call for (lookup model, training mode, coordinate labels, int32 device ids) against the
+    general path on the same inputs and dropout counters: loss and all_outputs bit for bit, gradients equal up to the order of the
+    prefix backward's float atomics, over two steps"""
+    from open_knowledge_graph_embeddings_amd import trainer as T
+    from open_knowledge_graph_embeddings_amd.hotpath import positives_from_dense
+    z = golden("g2_loss_complex_bce_all")
+    n_ent = z["E"].shape[0]
+    inputs = [(_dev(z["po_rel"]), _dev(z["po_obj"])), (_dev(z["sp_subj"]), _dev(z["sp_rel"]))]
+    ids_case = case.startswith("id_list")
+    cand = _dev(np.arange(2, n_ent, dtype=np.int32)[::2].copy().reshape(-1, 1)) if ids_case else _dev(z["cand"])
+    n = cand.numel()
+    labels = _dev(z["labels"])[:, :n].contiguous()
+    coords = positives_from_dense(labels)
+    loss_mod = torch.nn.KLDivLoss(reduction="sum") if case.endswith("kl") else torch.nn.BCEWithLogitsLoss(reduction="sum")
+    out = {}
+    for fast in (True, False):
+        monkeypatch.setattr(T, "FAST_CALL", fast)
+        m = _lookup_model(z, dropout=0.3)
+        m.train()
+        mod = T.AddLossModule(m, loss_mod, 0.1 if "smoothing" in case else 0.0, training_outputs="outputs" in case)
+        seen = []
+        for step in range(2):
+            m.zero_grad(set_to_none=True)
+            loss, hook, outs = mod(inputs=inputs, labels=coords, use_batch_shared_entities=ids_case, batch_shared_entities=cand, epoch=1,
+                                   input_style_triple_or_prefix="right_and_left_prefix")
+            (loss.sum() / float(labels.numel())).backward()
+            seen.append((loss.detach().clone(), None if outs is None else outs.clone(), m.entity_embedding.weight.grad.clone(),
+                         m.relation_embedding.weight.grad.clone()))
+        assert (getattr(mod, "_fd", None) is not None) == fast           # the fast call ran / did not run
+        out[fast] = seen
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a[0], b[0])
+        assert (a[1] is None and b[1] is None) or torch.equal(a[1], b[1])
+        # gradient rows that several batch rows add into with float atomics (every relation row; the few shared prefix entities)
+        # differ in the last bits from run to run of EITHER path; everything else is bit-equal
+        for x, y in ((a[2], b[2]), (a[3], b[3])):
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=0, atol=2e-6 * float(y.abs().max()))
+        assert float((a[2] != b[2]).float().mean()) < 0.02
+    assert not torch.equal(out[True][0][2], out[True][1][2])             # (the dropout counter moved on between the steps)
