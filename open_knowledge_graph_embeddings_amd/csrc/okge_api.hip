@@ -55,6 +55,8 @@ hipEvent_t get_event()
     return e;
 }
 
+constexpr int OKGE_MAX_DEVICES_SIDE = 64;
+
 struct ScopedTimer {
     hipStream_t st;
     bool        on;
@@ -76,6 +78,36 @@ struct ScopedTimer {
         g_launches.push_back(t);
     }
 };
+
+// ---- a side stream per (host thread, device): the partial-slab reduction of a training call BESIDE the dQ kernel -----------
+// An experiment, OFF unless OKGE_REDUCE_OVERLAP=1.  dc_reduce* is HBM-bound (17 us / 87 MB at configs[2], 9.5 us at configs[4]) and
+// the dQ kernel that follows it is MFMA-bound and needs nothing the reduction writes (it reads G^T and the masked candidate rows;
+// the reduction turns the tile kernel's partial slabs into dE rows): fork after the tile launch, join before whatever touches dE
+// or the slabs next (the prefix backward, the next range's tile launch); event record / wait pairs, captured as plain dependencies
+// when the caller's stream is capturing.  Correct (the whole GPU suite passes with it on) and SLOWER: next to the dQ kernel's
+// resident workgroups the reduction stretches 17 -> 66 us and the dQ kernel 54 -> 59 us: configs[2] 0.257 -> 0.276 ms, configs[4]
+// 0.728 -> 0.743, the 8-rank FB shape 0.154 -> 0.164 (profiles/round4_ablation.md section 7) -- like the two side-stream sweeps before.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t  fork = nullptr, join = nullptr;
+    bool        ok = false;
+};
+static SideStream *side_stream()
+{
+    static const bool enabled = std::getenv("OKGE_REDUCE_OVERLAP") && std::atoi(std::getenv("OKGE_REDUCE_OVERLAP")) == 1;
+    if (!enabled) return nullptr;
+    thread_local SideStream side[OKGE_MAX_DEVICES_SIDE];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= OKGE_MAX_DEVICES_SIDE) return nullptr;
+    SideStream &x = side[dev];
+    if (!x.s) {
+        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+        if (!x.s) x.s = reinterpret_cast<hipStream_t>(-1);       // (creation failed: never tried again, the reduction stays in line)
+    }
+    return x.ok ? &x : nullptr;
+}
 
 // ---- device word counting out-of-range ids (checked_row in the kernels); read and cleared by okge_id_errors ------------
 // One word PER DEVICE (keyed by hipGetDevice() at the call): a process that drives several devices must never hand a kernel
@@ -637,28 +669,41 @@ static int train_core(const okge_tables *t, const okge_shard *sh, const okge_pre
             if (e != hipSuccess) return fail_hip(e, "fused_tile_kernel<train>");
         }
         if (loss_only) continue;
+        // the partial slabs' reduction: on the side stream beside the dQ launch where there is one (see SideStream)
+        const bool reduce = tail_r > 0 || g.sk_wgs > 0 || g.b_split > 1;
+        SideStream *side = reduce ? side_stream() : nullptr;
+        hipStream_t rs = st;
+        if (side) {
+            if (hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess) rs = side->s;
+            else side = nullptr;
+        }
         if (tail_r > 0) {
-            ScopedTimer tm("dc_reduce", st);
+            ScopedTimer tm("dc_reduce", rs);
             e = launch_dc_reduce(a.dC_slab, g.tail_split, tail_r * NT, g.D16, at.N, g.d, at.cand_ids, at.cand_first, a.cand_exclusive,
-                                 a.grads_zero, dE, a.n_table_rows, a.id_err, st);
+                                 a.grads_zero, dE, a.n_table_rows, a.id_err, rs);
             if (e != hipSuccess) return fail_hip(e, "dc_reduce");
         }
         if (g.sk_wgs > 0) {
-            ScopedTimer tm("dc_reduce", st);
+            ScopedTimer tm("dc_reduce", rs);
             e = launch_dc_reduce_streamk(a.dC_slab, tiles_r, g.sk_chunks, g.sk_wgs, g.D16, ar.N, g.d, cand->ids, cand->first_id,
-                                         a.cand_exclusive, a.grads_zero, dE, a.n_table_rows, a.id_err, st);
+                                         a.cand_exclusive, a.grads_zero, dE, a.n_table_rows, a.id_err, rs);
             if (e != hipSuccess) return fail_hip(e, "dc_reduce_streamk");
         } else if (g.b_split > 1) {                 // (few candidate tiles: always a single range)
-            ScopedTimer tm("dc_reduce", st);
+            ScopedTimer tm("dc_reduce", rs);
             e = launch_dc_reduce(a.dC_slab, g.b_split, g.tiles * NT, g.D16, g.N, g.d, cand->ids, cand->first_id, a.cand_exclusive,
-                                 a.grads_zero, dE, a.n_table_rows, a.id_err, st);
+                                 a.grads_zero, dE, a.n_table_rows, a.id_err, rs);
             if (e != hipSuccess) return fail_hip(e, "dc_reduce");
         }
-        ScopedTimer tm("dq", st);
-        q.N = ar.N;
-        q.accumulate = r > 0 ? 1 : 0;               // later ranges add to the slabs of the first
-        e = launch_dq(q, (g.Bpad / BC) * g.nsplit, st);
-        if (e != hipSuccess) return fail_hip(e, "dq_kernel");
+        if (side && hipEventRecord(side->join, side->s) != hipSuccess) return fail(OKGE_ERR_HIP, "side stream: event record");
+        {
+            ScopedTimer tm("dq", st);
+            q.N = ar.N;
+            q.accumulate = r > 0 ? 1 : 0;           // later ranges add to the slabs of the first
+            e = launch_dq(q, (g.Bpad / BC) * g.nsplit, st);
+            if (e != hipSuccess) return fail_hip(e, "dq_kernel");
+        }
+        // join: the next range's tile launch rewrites the slabs, the prefix backward adds into dE rows the reduction stores
+        if (side && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return fail(OKGE_ERR_HIP, "side stream: event wait");
     }
     if (loss_only) {
         ScopedTimer tm("loss_reduce", st);
