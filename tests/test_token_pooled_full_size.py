@@ -205,3 +205,39 @@ def test_token_pooled_replica_step_one_rank_at_config5_size(okge_lib, problem, r
         _check(inner, reference, loss)
     finally:
         dist.destroy_process_group()
+
+
+def test_lazy_decay_at_config5_size(okge_lib, problem):
+    """deferred decay (decay_window = 8: okge_pool_catch_up_calls + okge_adagrad_lazy) against every-row-every-step (window 1) at
+    configs[4]'s real size: ten steps over four different batches (candidate lists and prefixes shifted through the entity ids: the
+    same rows are named again after four steps, others never), losses and -- after flush() -- tables and accumulators bit-equal.
+    What the size adds to tests/test_token_pooled.py: 164 k (row, position) pairs per step of which half name the padding row,
+    tens of thousands of claims per catch-up, every workgroup of the rotating sweep busy, rows of both the generic and the packed
+    replay arithmetic (elements with |p| < 3e-5 keep their accumulator below 2^-96)"""
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    z = problem
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()           # noqa: E731
+    ent_tok, rel_tok = t(z["ent_tokens"]), t(z["rel_tokens"])
+
+    def make(window):
+        e = TokenSlot(t(z["We"]), ent_tok, "sum", True, t(z["bn_e_w"]), t(z["bn_e_b"]))
+        r = TokenSlot(t(z["Wr"]), rel_tok, "sum", True, t(z["bn_r_w"]), t(z["bn_r_b"]))
+        return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=P_DROP, seed=SEED, decay_window=window), e, r
+    a, b_ = make(8), make(1)
+    shift = lambda x, k, n: (2 + (x.astype(np.int64) - 2 + 7919 * k) % (n - 2)).astype(np.int32)      # noqa: E731
+    batches = [PrefixBatch(po_rel=t(shift(z["po_rel"], k, N_REL)), po_obj=t(shift(z["po_obj"], k, N_ENT)),
+                           sp_subj=t(shift(z["sp_subj"], k, N_ENT)), sp_rel=t(shift(z["sp_rel"], k, N_REL)),
+                           pos_row=t(z["pos_row"]), pos_col=t(z["pos_col"]), cand_ids=t(shift(z["cand"], k, N_ENT))) for k in range(4)]
+    for step in range(10):
+        la = float(a[0].step(batches[step % 4])[0])
+        lb = float(b_[0].step(batches[step % 4])[0])
+        assert la == lb, (step, la, lb)
+    lag = int(a[0]._counters[0]) - a[1].row_steps
+    assert 0 < int(lag.max()) <= 8 and int((lag > 0).sum()) > V_ENT // 2          # most rows owe steps at this point
+    a[0].flush()
+    torch.cuda.synchronize()
+    for x, y in ((a[1], b_[1]), (a[2], b_[2])):
+        assert torch.equal(x.W, y.W) and torch.equal(x.sumW, y.sumW) and torch.equal(x.bn, y.bn) and torch.equal(x.sum_bn, y.sum_bn)
+    from open_knowledge_graph_embeddings_amd import _native as N
+    N.check_ids()
