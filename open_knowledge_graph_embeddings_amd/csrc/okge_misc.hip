@@ -894,7 +894,7 @@ struct LazySegsDev { LazySeg s[ADAGRAD_MAX_SEGS]; int n; int64_t batch0[ADAGRAD_
 constexpr int LAZY_BATCH = 16;         // rows per wave and turn: many short turns hide the rows' load latency
 
 __device__ __forceinline__ void adagrad_lazy_body(const LazySegsDev &segs, int32_t *counters, int window, int mode, float lr, float wd,
-                                                  float eps)
+                                                  float eps, int lazy_batch)
 {
     const int T = counters[0], target = mode == LAZY_STEP ? T + 1 : T;
     const int lane = threadIdx.x & 63;
@@ -906,8 +906,8 @@ __device__ __forceinline__ void adagrad_lazy_body(const LazySegsDev &segs, int32
         int k = 0;
         while (b >= segs.batch0[k + 1]) ++k;
         const LazySeg &sg = segs.s[k];
-        const int64_t r = (b - segs.batch0[k]) * LAZY_BATCH + (lane & (LAZY_BATCH - 1));
-        const bool in = lane < LAZY_BATCH && r < sg.rows;
+        const int64_t r = (b - segs.batch0[k]) * lazy_batch + (lane & (lazy_batch - 1));
+        const bool in = lane < lazy_batch && r < sg.rows;
         const int up = in ? sg.steps[r] : target;
         const bool stamped = mode == LAZY_STEP && in && sg.touched && sg.touched[r] == (uint8_t)sg.stamp;
         const bool due = in && (mode == LAZY_FLUSH || (int)((uint32_t)r % (uint32_t)window) == phase);      // (rows < 2^31: okge_api.hip)
@@ -944,9 +944,9 @@ __device__ __forceinline__ void adagrad_lazy_body(const LazySegsDev &segs, int32
 // 93 registers = 5 waves per SIMD.  Budgets of 80 / 64 registers (6 / 8 waves) spill inside the replay loops: 85 / 130 us against
 // 70 us at configs[4] (profiles/round4_ablation.md section 6)
 __global__ __launch_bounds__(256, 5) void adagrad_lazy_kernel(const LazySegsDev segs, int32_t *counters, int window, int mode, float lr,
-                                                           float wd, float eps)
+                                                           float wd, float eps, int lazy_batch)
 {
-    adagrad_lazy_body(segs, counters, window, mode, lr, wd, eps);
+    adagrad_lazy_body(segs, counters, window, mode, lr, wd, eps, lazy_batch);
 }
 
 constexpr int RANK_GROUPS = 8;
@@ -1479,13 +1479,15 @@ hipError_t launch_adagrad_lazy(const LazySeg *segs, int n_segs, int32_t *counter
     LazySegsDev a;
     std::memset(&a, 0, sizeof(a));
     a.n = n_segs;
+    static const int lazy_batch_env = getenv("OKGE_LAZY_BATCH") ? atoi(getenv("OKGE_LAZY_BATCH")) : LAZY_BATCH;
+    const int lazy_batch = (lazy_batch_env == 8 || lazy_batch_env == 32 || lazy_batch_env == 64) ? lazy_batch_env : LAZY_BATCH;
     for (int k = 0; k < n_segs; ++k) {
         a.s[k] = segs[k];
-        a.batch0[k + 1] = a.batch0[k] + (segs[k].steps ? (segs[k].rows + LAZY_BATCH - 1) / LAZY_BATCH : 0);
+        a.batch0[k + 1] = a.batch0[k] + (segs[k].steps ? (segs[k].rows + lazy_batch - 1) / lazy_batch : 0);
     }
     // (every wave resident: 5 per SIMD; a wave takes batch after batch)
     const int64_t wgs = std::max<int64_t>(1, std::min<int64_t>((a.batch0[n_segs] + 3) / 4, 256 * 5));
-    hipLaunchKernelGGL(adagrad_lazy_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a, counters, window, mode, lr, wd, eps);
+    hipLaunchKernelGGL(adagrad_lazy_kernel, dim3((unsigned)wgs), dim3(256), 0, st, a, counters, window, mode, lr, wd, eps, lazy_batch);
     return hipGetLastError();
 }
 

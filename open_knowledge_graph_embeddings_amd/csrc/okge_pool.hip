@@ -374,19 +374,19 @@ __global__ __launch_bounds__(256) void pool_stats_kernel(const PoolBatch pb, int
 constexpr int CATCH_ROWS = 8, CATCH_PAIRS = 16;
 
 __global__ __launch_bounds__(256, 8) void pool_catch_up_kernel(const PoolBatch pb, const int32_t *__restrict__ counters, float lr, float wd,
-                                                            float eps)
+                                                            float eps, int catch_rows, int catch_pairs)
 {
     int lb;
     const PoolCall &q = pb.c[locate_call(pb, blockIdx.x, lb)];
     if (!q.steps) return;
     const int T = counters[0];
-    const int L = q.L, r0 = lb * CATCH_ROWS, nr = min(q.n, r0 + CATCH_ROWS) - r0, lane = threadIdx.x & 63;
+    const int L = q.L, r0 = lb * catch_rows, nr = min(q.n, r0 + catch_rows) - r0, lane = threadIdx.x & 63;
     float *W = const_cast<float *>(q.W);
     // CATCH_PAIRS pairs per wave and turn: many short waves, like adagrad_lazy_kernel
-    for (int i0 = (threadIdx.x >> 6) * CATCH_PAIRS; i0 < nr * L; i0 += 4 * CATCH_PAIRS) {
+    for (int i0 = (threadIdx.x >> 6) * catch_pairs; i0 < nr * L; i0 += 4 * catch_pairs) {
         const int i = i0 + lane;
         int tok = -1, from = T;
-        if (lane < CATCH_PAIRS && i < nr * L) tok = q.tokens[(size_t)row_id(q.ids, q.first_id, r0 + i / L, q.n_ids, nullptr) * L + i % L];
+        if (lane < catch_pairs && i < nr * L) tok = q.tokens[(size_t)row_id(q.ids, q.first_id, r0 + i / L, q.n_ids, nullptr) * L + i % L];
         if (tok == 0) tok = -1;                                  // (below: the call's first workgroup looks after row 0)
         bool claim = false;
         if ((unsigned)tok < (unsigned)q.vocab && q.steps[tok] < T) {
@@ -1127,8 +1127,12 @@ hipError_t launch_pool_catch_up(const PoolCall *calls, int n_calls, const int32_
 {
     if (n_calls <= 0) return hipSuccess;
     if (n_calls > POOL_MAX_CALLS || !counters) return hipErrorInvalidValue;
-    const PoolBatch pb = make_batch(calls, n_calls, id_err, [](const PoolCall &q) { return (q.n + CATCH_ROWS - 1) / CATCH_ROWS; });
-    hipLaunchKernelGGL(pool_catch_up_kernel, dim3(pb.cum[n_calls]), dim3(256), 0, st, pb, counters, lr, wd, eps);
+    static const int rows_env = getenv("OKGE_CATCH_ROWS") ? atoi(getenv("OKGE_CATCH_ROWS")) : CATCH_ROWS;
+    static const int pairs_env = getenv("OKGE_CATCH_PAIRS") ? atoi(getenv("OKGE_CATCH_PAIRS")) : CATCH_PAIRS;
+    const int catch_rows = rows_env >= 1 && rows_env <= 64 ? rows_env : CATCH_ROWS;
+    const int catch_pairs = (pairs_env == 8 || pairs_env == 32 || pairs_env == 64) ? pairs_env : CATCH_PAIRS;
+    const PoolBatch pb = make_batch(calls, n_calls, id_err, [catch_rows](const PoolCall &q) { return (q.n + catch_rows - 1) / catch_rows; });
+    hipLaunchKernelGGL(pool_catch_up_kernel, dim3(pb.cum[n_calls]), dim3(256), 0, st, pb, counters, lr, wd, eps, catch_rows, catch_pairs);
     return hipGetLastError();
 }
 
