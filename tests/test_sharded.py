@@ -905,7 +905,7 @@ def _token_pooled_tables(n_ids=300, n_rel=30, vocab=80, L=4, d=64):
                 te=tok(n_ids), tr=tok(n_rel), bw=rng.random(d).astype(np.float32), bb=(rng.standard_normal(d) * 0.1).astype(np.float32))
 
 
-def _nccl_replica_worker(rank, world, port, outdir, nsteps):
+def _nccl_replica_worker(rank, world, port, outdir, nsteps, backend="nccl"):
     """ReplicaStep(sparse=True) around the token-pooled step on real streams: side-stream mask all-reduce, packed touched-row
     exchange, the touched-row map of the optimizer sweep stamped for the OTHER replica's rows"""
     sys.path.insert(0, ROOT)
@@ -915,10 +915,14 @@ def _nccl_replica_worker(rank, world, port, outdir, nsteps):
     from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch
     from open_knowledge_graph_embeddings_amd.sharded import ReplicaStep
     from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
-    dev = torch.device("cuda", rank)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)          # gloo: both ranks share the one GPU of the box
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev,
-                            timeout=datetime.timedelta(minutes=5))
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(minutes=5))
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(minutes=5))
     z = _token_pooled_tables()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
     e = TokenSlot(t(z["We"]), t(z["te"]), "sum", True, t(z["bw"]), t(z["bb"]))
@@ -956,6 +960,32 @@ def test_replica_step_sparse_two_ranks_rccl(okge_lib):
     assert (parts[0]["sent"] < parts[0]["dense"]).all() and (parts[0]["sent"] == parts[1]["sent"]).all()
     z = _token_pooled_tables()
     assert np.abs(parts[0]["We"] - z["We"]).max() > 1e-3                # the tables moved
+
+
+@pytest.mark.gpu
+def test_replica_step_sparse_two_ranks_one_gpu_deferred_decay(okge_lib, monkeypatch):
+    """the same two-rank token-pooled replica run over gloo with both ranks on ONE GPU (runs on every box), seven steps, once
+    with the deferred decay (default window 8) and once with every row every step: a replica catches up only the rows of ITS
+    batch before the forward; the other replica's rows arrive stamped through the exchange and take what they owe inside the
+    update -- both ranks must hold identical tables, and the deferred run must equal the eager one bit for bit after flush()"""
+    import torch.multiprocessing as mp
+    world, nsteps = 2, 7
+    runs = {}
+    for window in ("8", "1"):
+        monkeypatch.setenv("OKGE_LAZY_DECAY", window)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        with tempfile.TemporaryDirectory() as outdir:
+            mp.spawn(_nccl_replica_worker, args=(world, port, outdir, nsteps, "gloo"), nprocs=world, join=True)
+            parts = [dict(np.load(os.path.join(outdir, f"rank{r}.npz"))) for r in range(world)]
+        for k in ("We", "Wr", "bn", "rm"):
+            np.testing.assert_array_equal(parts[0][k], parts[1][k])
+        runs[window] = parts[0]
+    for k in ("We", "Wr", "bn", "rm"):
+        np.testing.assert_array_equal(runs["8"][k], runs["1"][k])
+    z = _token_pooled_tables()
+    assert np.abs(runs["8"]["We"] - z["We"]).max() > 1e-3
 
 
 @pytest.mark.gpu
