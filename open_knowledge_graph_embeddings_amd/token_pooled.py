@@ -212,7 +212,7 @@ class TokenPooledTrainStep:
     def __init__(self, entity: TokenSlot, relation: TokenSlot, scorer, loss="bce", lr=0.1, weight_decay=1e-10, eps=1e-8,
                  label_smoothing=0.0, dropout=0.0, seed=0, engine=None, overlap_sweep=None, decay_window=None):
         self.entity, self.relation, self.scorer, self.loss = entity, relation, scorer, loss
-        # decay_window (OKGE_LAZY_DECAY, default 8; 1 = every row every step): the reference's Adagrad moves EVERY token row in
+        # decay_window (OKGE_LAZY_DECAY; 1 = every row every step): the reference's Adagrad moves EVERY token row in
         # every step by its weight-decay term (utils/optim.py:139-160) -- 1 GB of read-modify-write at configs[4], 175 us of a
         # 0.78 ms step, for rows nothing reads.  With a window W > 1 a row no batch names takes its pending decay-only steps
         # later, all at once in registers (okge_adagrad_lazy, okge.h): when a batch names it (catch-up before the forward),
@@ -221,8 +221,13 @@ class TokenPooledTrainStep:
         # batch named may lag by up to W - 1 decay-only steps; everything in this package that reads the tables (evaluation,
         # state_tensors / checkpoints, the module's encode methods and state_dict) calls flush() first -- do the same before
         # reading .W / .sumW directly, and before DISCARDING a step object whose tables live on (its pending steps go with it).
+        # Default: window 8 for token tables of 96 MB and more, 1 below -- the deferral trades the sweep's HBM time (0.7 us per MB of
+        # table) for a catch-up launch and replay arithmetic that do not shrink with the table: at 45 MB it LOSES 40 us per step
+        # (tools/soak_lazy.py), at configs[4]'s 256 MB it wins 130.
         if decay_window is None:
-            decay_window = int(os.environ.get("OKGE_LAZY_DECAY", "8"))
+            env = os.environ.get("OKGE_LAZY_DECAY")
+            big = (entity.W.numel() + relation.W.numel()) * 4 >= (96 << 20)
+            decay_window = int(env) if env else (8 if big else 1)
         lazy_ok = all(getattr(sl, "row_steps", None) is not None and getattr(sl, "touched", None) is not None for sl in (entity, relation))
         self.decay_window = max(1, int(decay_window)) if lazy_ok else 1
         self._counters = torch.zeros(2, dtype=torch.int32, device=entity.W.device)      # [optimizer steps taken, scratch]

@@ -475,7 +475,7 @@ def test_module_readers_flush_the_training_driver(okge_lib):
         m = UnigramPoolingComplexRelationModel(entity_slot_size=d, relation_slot_size=d, train_data=md, pool="sum", normalize="batchnorm",
                                                dropout=0.0, init_std=0.3).cuda()
         st = m.train_step(lr=0.1)
-        st.decay_window = window if st.decay_window > 1 else 1
+        st.decay_window = window                # (tables this small default to 1)
         r2 = np.random.default_rng(4)
         for _ in range(5):
             st.step(_lazy_batch(r2, n_ent=n_ent, n_rel=n_rel, N=64, B=32))
