@@ -518,9 +518,19 @@ def test_fast_decay_arithmetic_is_the_generic_one(okge_lib, window):
         maps = torch.zeros(rows, dtype=torch.uint8, device="cuda")
         cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
         lazy = [(pl, gl, sl, steps_, maps, 1)]
-        for _ in range(7):
+        for step in range(7):
+            # a third of the rows carry a gradient (stamped in the lazy run): ordinary magnitudes in the first rows, twenty
+            # orders of magnitude and zeros elsewhere -- the step with a gradient has a packed copy too (adagrad4_ordinary)
+            sel = torch.rand(rows, device="cuda", generator=g) < 0.33
+            grad = sign * u(-14, 3)
+            grad[:2048] = (sign * u(-7, -1))[:2048]
+            grad[:, step::11] = 0.0
+            for gbuf in (ge, gl):
+                gbuf[sel] = grad[sel]
+            maps[sel] = 1
             eng.adagrad_multi([(pe, ge, se)], lr, wd, eps)
             eng.adagrad_lazy(lazy, cnt, window, False, lr, wd, eps)
+            assert int(maps.max()) == 0 and float(gl.abs().max()) == 0.0 and float(ge.abs().max()) == 0.0
         eng.adagrad_lazy(lazy, cnt, window, True, lr, wd, eps)
         torch.cuda.synchronize()
         assert int(cnt[0]) == 7 and int(steps_.min()) == 7
