@@ -519,8 +519,8 @@ def test_fast_decay_arithmetic_is_the_generic_one(okge_lib, window):
         cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
         lazy = [(pl, gl, sl, steps_, maps, 1)]
         for step in range(7):
-            # a third of the rows carry a gradient (stamped in the lazy run): ordinary magnitudes in the first rows, twenty
-            # orders of magnitude and zeros elsewhere -- the step with a gradient has a packed copy too (adagrad4_ordinary)
+            # a third of the rows carry a gradient (stamped in the lazy run: what they owe, then the step with the gradient):
+            # ordinary magnitudes in the first rows, twenty orders of magnitude and zeros elsewhere
             sel = torch.rand(rows, device="cuda", generator=g) < 0.33
             grad = sign * u(-14, 3)
             grad[:2048] = (sign * u(-7, -1))[:2048]
