@@ -46,6 +46,10 @@ Vectors:
   g15_epochs      three whole training passes of the reference over its own loader (test.txt as the training split, shuffle off,
                   dropout 0): per-step loss / normalizer, rows and positives per batch; then its evaluation over all of
                   valid.txt on the trained fp32 tables: meters
+  g16_unigram_adagrad  the token-pooled model (sum pooling + batch-norm) through TWELVE optimisation steps of the reference's own
+                  OptimRegime Adagrad (weight_decay 1e-10, leaked eps) on different batches: per-step loss, final token tables,
+                  accumulators and batch-norm parameters -- in particular the rows NO batch names, which the reference's dense
+                  optimizer moves every step by their weight-decay term alone (what okge_adagrad_lazy defers and replays)
   g11_traj_*      30 training steps at the BASELINE size on real FB15k-237 batches (reference dataset + collate), then
                   filtered ranks / MRR of the first valid.txt batch on the trained tables
 """
@@ -1142,9 +1146,66 @@ def g8():
     torch.save(state, os.path.join(OUT, "g8_checkpoint_after.pt"))
 
 
+def g16():
+    rng = np.random.default_rng(1600)
+    n_ent, n_rel, d, b_po, b_sp, n_cand, L, vt_e, vt_r, nsteps = 220, 14, 24, 9, 10, 48, 6, 300, 40, 12
+
+    def token_map(n, vocab, hi):                             # body tokens from [4, hi): ids >= hi are never named by anything
+        out = [[1], [1]]
+        for _ in range(2, n):
+            k = int(rng.integers(1, L))
+            out.append([2] + rng.integers(4, hi, size=k).tolist() + [3])
+        return tuple(out)
+    md = meta(n_ent, n_rel)
+    md.entity_id_to_tokens_map, md.relation_id_to_tokens_map = token_map(n_ent, vt_e, 200), token_map(n_rel, vt_r, 30)
+    md.entity_tokens_size, md.relation_tokens_size, md.max_length = vt_e, vt_r, (L, L)
+    torch.manual_seed(1600)
+    m = Models.UnigramPoolingComplexRelationModel(entity_slot_size=d, relation_slot_size=d, train_data=md, pool="sum",
+                                                  normalize="batchnorm", dropout=0.0, sparse=False, init_std=0.3)
+    m.entity_projection = None                               # harness shim, see the module docstring
+    m.train()
+    args = {"optimization_config": {"optimizer": "Adagrad", "epoch": 0, "lr": 0.1, "weight_decay": 1.0e-10}, "lr_scheduler_config": None}
+    opts = OptimRegime.setup_optimizer_regime(args=args, model=m)
+    mod = AddLossModule(m, torch.nn.BCEWithLogitsLoss(reduction="sum"), 0.0)
+    mod.train()
+    kw = dict(We=npy(m.entity_embedding.weight).copy(), Wr=npy(m.relation_embedding.weight).copy(),
+              ent_tokens=npy(m.entity_token_ids).astype(np.int32), rel_tokens=npy(m.relation_token_ids).astype(np.int32),
+              bn_e_w=npy(m.entity_batchnorm.weight).copy(), bn_e_b=npy(m.entity_batchnorm.bias).copy(),
+              bn_r_w=npy(m.relation_batchnorm.weight).copy(), bn_r_b=npy(m.relation_batchnorm.bias).copy(), nsteps=np.int64(nsteps))
+    B = b_po + b_sp
+    for step in range(nsteps):
+        lo = 2 + (step % 4) * 50                              # the batches move through the entity ids: rows go cold and come back
+        cand = torch.from_numpy((lo + rng.permutation(60)[:n_cand]).astype(np.int32)).unsqueeze(1)
+        po = (rand_ids(rng, 2, n_rel, b_po), rand_ids(rng, lo, lo + 60, b_po))
+        sp = (rand_ids(rng, lo, lo + 60, b_sp), rand_ids(rng, 2, n_rel, b_sp))
+        y = dense_labels(rng, B, n_cand)
+        for o in opts:
+            o.update(1, step + 1)
+            o.zero_grad()
+        loss, _, _ = mod(inputs=[po, sp], labels=torch.from_numpy(y.copy()), use_batch_shared_entities=True, batch_shared_entities=cand,
+                         epoch=1, input_style_triple_or_prefix="right_and_left_prefix")
+        (loss.sum() / float(B * n_cand)).backward()
+        for o in opts:
+            o.step()
+        kw.update({f"s{step}_cand": npy(cand), f"s{step}_po_rel": npy(po[0]), f"s{step}_po_obj": npy(po[1]), f"s{step}_sp_subj": npy(sp[0]),
+                   f"s{step}_sp_rel": npy(sp[1]), f"s{step}_labels": y, f"s{step}_loss": np.float64(loss.item())})
+    g = opts[0].optimizer.param_groups[0]
+    st = opts[0].optimizer.state
+    kw.update({"opt_" + k: np.float64(g[k]) for k in ("lr", "eps", "weight_decay")})
+    kw.update(We_end=npy(m.entity_embedding.weight).copy(), Wr_end=npy(m.relation_embedding.weight).copy(),
+              sumWe_end=npy(st[m.entity_embedding.weight]["sum"]).copy(), sumWr_end=npy(st[m.relation_embedding.weight]["sum"]).copy(),
+              bn_e_w_end=npy(m.entity_batchnorm.weight).copy(), bn_e_b_end=npy(m.entity_batchnorm.bias).copy(),
+              run_e_mean_end=npy(m.entity_batchnorm.running_mean).copy(), run_e_var_end=npy(m.entity_batchnorm.running_var).copy())
+    named = np.zeros(vt_e, bool)
+    named[np.unique(npy(m.entity_token_ids))] = True
+    print("g16: entity token rows never named:", int((~named).sum()), "of", vt_e, "| moved by the optimizer:",
+          float(np.abs(kw["We_end"][~named] - kw["We"][~named]).max()))
+    save("g16_unigram_adagrad", **kw)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]                      # e.g. `make_golden.py g1_triples` regenerates one family
-    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15):
+    for fn in (g1, g1_triples, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11, g12, g13, g14, g15, g16):
         if fn is g12 and any(a.startswith("g12:") for a in only):    # `make_golden.py g12:all_noshare`: one case of the family
             fn(tuple(a[4:] for a in only if a.startswith("g12:")))
         elif not only or fn.__name__ in only:

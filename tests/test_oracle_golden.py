@@ -380,3 +380,21 @@ def test_g9_unigram_oracle_matches_reference(name):
         return x if bn is None else ko.batchnorm_eval(x, bn["weight"], bn["bias"], bn["running_mean"], bn["running_var"])
     np.testing.assert_allclose(table(z["We"], z["ent_tokens"], bn_e), z["E_eval"], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(table(z["Wr"], z["rel_tokens"], bn_r), z["R_eval"], rtol=1e-5, atol=2e-6)
+
+
+def test_g16_rows_no_batch_names_move_under_the_reference_optimizer():
+    """G16 (token-pooled model, twelve steps of the reference's OptimRegime Adagrad): 107 of the 300 entity token rows are named by
+    no entity.  The reference's dense optimizer moves them all the same -- by their weight-decay term, up to 0.013 over the run --
+    and the oracle's Adagrad, fed zero gradients for those rows, lands on the reference's values and accumulators: the update
+    okge_adagrad_lazy defers and replays is the reference's, not an artefact of this build."""
+    z = golden("g16_unigram_adagrad")
+    named = np.zeros(z["We"].shape[0], bool)
+    named[np.unique(z["ent_tokens"])] = True
+    assert (~named).sum() == 107
+    moved = np.abs(z["We_end"][~named] - z["We"][~named])
+    assert moved.max() > 0.01 and (moved > 0).mean() > 0.99 and float(z["opt_eps"]) == 1e-8 and float(z["opt_weight_decay"]) == 1e-10
+    p, s = z["We"][~named].copy(), np.zeros_like(z["We"][~named])
+    for _ in range(int(z["nsteps"])):
+        ko.adagrad_step(p, np.zeros_like(p), s, float(z["opt_lr"]), float(z["opt_weight_decay"]), float(z["opt_eps"]))
+    np.testing.assert_allclose(p, z["We_end"][~named], rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(s, z["sumWe_end"][~named], rtol=2e-6, atol=1e-32)

@@ -538,3 +538,44 @@ def test_fast_decay_arithmetic_is_the_generic_one(okge_lib, window):
         assert bool(same_p.all()) and bool(same_s.all()), (lr, wd, eps, int((~same_p).sum()), int((~same_s).sum()),
                                                            (~(same_p & same_s)).any(dim=1).nonzero()[:8].flatten().tolist())
         assert not torch.equal(pe, p)                         # (the steps did move the table)
+
+
+@pytest.mark.parametrize("window", [1, 3, 8])
+def test_twelve_reference_optimizer_steps_with_rows_no_batch_names(okge_lib, window):
+    """G16: the reference's UnigramPoolingComplexRelationModel through twelve steps of ITS OWN OptimRegime Adagrad (weight_decay
+    1e-10, the leaked eps 1e-8) on batches that move through the entity ids.  107 of the 300 entity token rows are named by no
+    entity at all -- the reference's dense optimizer still moves them, every step, by their weight-decay term alone (up to 0.013
+    over the run): the premise of okge_adagrad_lazy.  This build, with every window: the first loss within 5e-5, the never-named
+    rows and their accumulators within a few ulps per step of the reference's (same IEEE operations; torch rounds g*g and
+    lr*(g/std) separately where the kernels use fused multiply-adds); the named rows only coarsely (see the loop)."""
+    from open_knowledge_graph_embeddings_amd.hotpath import PrefixBatch, positives_from_dense
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    z = golden("g16_unigram_adagrad")
+    e = TokenSlot(dev(z["We"]), dev(z["ent_tokens"]), "sum", True, dev(z["bn_e_w"]), dev(z["bn_e_b"]))
+    r = TokenSlot(dev(z["Wr"]), dev(z["rel_tokens"]), "sum", True, dev(z["bn_r_w"]), dev(z["bn_r_b"]))
+    st = TokenPooledTrainStep(e, r, "complex", lr=float(z["opt_lr"]), weight_decay=float(z["opt_weight_decay"]), eps=float(z["opt_eps"]),
+                              decay_window=window)
+    assert st.decay_window == window and float(z["opt_eps"]) == 1e-8
+    for s in range(int(z["nsteps"])):
+        b = PrefixBatch(po_rel=dev(z[f"s{s}_po_rel"].reshape(-1)), po_obj=dev(z[f"s{s}_po_obj"].reshape(-1)),
+                        sp_subj=dev(z[f"s{s}_sp_subj"].reshape(-1)), sp_rel=dev(z[f"s{s}_sp_rel"].reshape(-1)),
+                        cand_ids=dev(z[f"s{s}_cand"].reshape(-1).astype(np.int32)))
+        b.pos_row, b.pos_col = positives_from_dense(dev(z[f"s{s}_labels"]))
+        loss = float(st.step(b)[0])
+        # the first step is the reference's to 5e-5; from the second on the runs are different samples of an ill-conditioned
+        # trajectory -- Adagrad's first steps turn gradient entries of rounding-noise size (batch-norm makes the gradient of a
+        # token that stands in every row cancel to ~1e-9) into +-lr * g / (|g| + 1e-8) ~ 0.01 moves.  The oracle's own curve
+        # leaves the reference's by up to 0.9 % in float64 and 1.7 % in float32 over these twelve steps (same algorithm, other
+        # rounding); this build by about 2 %
+        assert abs(loss - float(z[f"s{s}_loss"])) <= (5e-5 if s == 0 else 6e-2) * abs(float(z[f"s{s}_loss"])), (s, loss, float(z[f"s{s}_loss"]))
+    st.flush()
+    torch.cuda.synchronize()
+    named = np.zeros(z["We"].shape[0], bool)
+    named[np.unique(z["ent_tokens"])] = True
+    W, S = e.W.cpu().numpy(), e.sumW.cpu().numpy()
+    assert (~named).sum() == 107 and np.abs(z["We_end"][~named] - z["We"][~named]).max() > 0.01     # the reference moved them
+    np.testing.assert_allclose(W[~named], z["We_end"][~named], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(S[~named], z["sumWe_end"][~named], rtol=2e-5, atol=1e-30)
+    diff = np.abs(W[named] - z["We_end"][named])
+    print("named rows: share within 1e-3:", float((diff < 1e-3).mean()), "max:", float(diff.max()))
+    assert (diff < 0.05).mean() > 0.9 and diff.max() < 12 * float(z["opt_lr"])         # coarse: see above
