@@ -1,5 +1,7 @@
 #!/bin/bash
 # round-4 helper (GPU box): configs[4] with the lazy update kernel under three register budgets, same box
+# (the 6- and 8-wave instances it selected with OKGE_LAZY_WAVES were removed after this measurement: profiles/round4_ablation.md section 6;
+#  what remains useful is the deferred-vs-eager A/B at the end)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r4
 mkdir -p $O
