@@ -112,6 +112,16 @@ def measure_config(name, dev, warmup=50, steps=200, peak_tflops=157.3):
     if tile_us:
         res["tile_us"] = tile_us
         res["tile_frac"] = flops_tile / (tile_us * 1e-6) / 1e12 / peak_tflops
+    if name == "S-OLP-tok":
+        # the same step on the Adagrad state of a run in progress (every accumulator has seen a real gradient: a decay-only update
+        # then returns its input bits -- main() below, "accumulators of a run in progress"), and what the optimizer does per step
+        res["decay_window"] = step.decay_window
+        step.flush()
+        for sl in (step.entity, step.relation):
+            sl.sumW.fill_(1e-4)
+        warm = run(name, step, batches, steps=steps, warmup=warmup, ksteps=10, quiet=True)
+        res["ms_per_step_warm_accumulators"] = warm["ms_per_step"]
+        res["adagrad_us_warm_accumulators"] = warm["kernels_us"].get("adagrad")
     del step, batches
     torch.cuda.empty_cache()
     return res
