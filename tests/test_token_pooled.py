@@ -579,3 +579,28 @@ def test_twelve_reference_optimizer_steps_with_rows_no_batch_names(okge_lib, win
     diff = np.abs(W[named] - z["We_end"][named])
     print("named rows: share within 1e-3:", float((diff < 1e-3).mean()), "max:", float(diff.max()))
     assert (diff < 0.05).mean() > 0.9 and diff.max() < 12 * float(z["opt_lr"])         # coarse: see above
+
+
+@pytest.mark.parametrize("pool", ["max", "sum_atomics"])
+def test_lazy_decay_on_the_atomics_backward(okge_lib, monkeypatch, pool):
+    """the deferred decay behind the float-atomic token-table scatter (max pooling always takes it; OKGE_POOL_SCATTER=atomics for
+    the others): the backward's sums differ in the last bits from run to run there, so the rows a batch names are compared to a
+    tolerance -- but every row NO batch named must still equal the eager run bit for bit after flush(), and the map must be clean"""
+    if pool == "sum_atomics":
+        monkeypatch.setenv("OKGE_POOL_SCATTER", "atomics")
+    rng = np.random.default_rng(41)
+    c = _plan_case(rng, d=64, L=5, n_ent=900, vt_e=6000, N=300, n_po=48, n_sp=48, pool="max" if pool == "max" else "sum", bn=True)
+    a, b_ = _plan_step(c, decay_window=4), _plan_step(c, decay_window=1)
+    assert a[0].decay_window == 4 and not (pool == "max" and a[0].pool.scatter_plan([(a[1],)]))
+    for _ in range(7):
+        a[0].step(a[3])
+        b_[0].step(b_[3])
+    a[0].flush()
+    torch.cuda.synchronize()
+    named = torch.zeros(c["We"].shape[0], dtype=torch.bool, device="cuda")
+    ids = torch.cat([dev(c["cand"]), dev(c["po"][1]), dev(c["sp"][0])]).long()
+    named[dev(c["ent_tok"])[ids].reshape(-1).long()] = True
+    assert int((~named).sum()) > 1000
+    assert torch.equal(a[1].W[~named], b_[1].W[~named]) and torch.equal(a[1].sumW[~named], b_[1].sumW[~named])
+    np.testing.assert_allclose(a[1].W[named].cpu().numpy(), b_[1].W[named].cpu().numpy(), rtol=1e-3, atol=1e-4)
+    assert int(a[1].touched.max()) == 0 and float(a[1].dW.abs().max()) == 0.0
