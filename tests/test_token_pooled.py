@@ -604,3 +604,31 @@ def test_lazy_decay_on_the_atomics_backward(okge_lib, monkeypatch, pool):
     assert torch.equal(a[1].W[~named], b_[1].W[~named]) and torch.equal(a[1].sumW[~named], b_[1].sumW[~named])
     np.testing.assert_allclose(a[1].W[named].cpu().numpy(), b_[1].W[named].cpu().numpy(), rtol=1e-3, atol=1e-4)
     assert int(a[1].touched.max()) == 0 and float(a[1].dW.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("d", [8, 200, 512])
+def test_lazy_decay_other_slot_sizes(okge_lib, d):
+    """the deferred decay at slot sizes other than 64 / 256: rows of 2 and 50 column quads (part of a wave idle) and of 128 (two
+    trips per row: the column loop of lazy_rows) -- bit-equal to the eager sweep after seven steps of moving batches"""
+    from open_knowledge_graph_embeddings_amd.token_pooled import TokenPooledTrainStep, TokenSlot
+    rng = np.random.default_rng(50 + d)
+    c = _plan_case(rng, d=d, L=5, n_ent=1500, vt_e=4000, N=256, n_po=32, n_sp=32, bn=True)
+
+    def make(window):
+        e = TokenSlot(dev(c["We"]), dev(c["ent_tok"]), "sum", True, dev(c["bn_e"]["weight"]), dev(c["bn_e"]["bias"]))
+        r = TokenSlot(dev(c["Wr"]), dev(c["rel_tok"]), "sum", True, dev(c["bn_r"]["weight"]), dev(c["bn_r"]["bias"]))
+        return TokenPooledTrainStep(e, r, "complex", lr=0.1, dropout=0.0, seed=3, decay_window=window), e, r
+    a, b_ = make(3), make(1)
+    r2 = np.random.default_rng(8)
+    for step in range(7):
+        lo = 2 + (step % 3) * 400
+        st0 = r2.bit_generator.state
+        losses = []
+        for st, _, _ in (a, b_):
+            r2.bit_generator.state = st0
+            losses.append(float(st.step(_lazy_batch(r2, n_ent=lo + 600, N=256, B=64, lo=lo))[0]))
+        assert losses[0] == losses[1], (step, losses)
+    assert int((int(a[0]._counters[0]) - a[1].row_steps).max()) > 0
+    a[0].flush()
+    torch.cuda.synchronize()
+    _same_tables(a, b_)
